@@ -1,0 +1,122 @@
+/*
+ * gradtts_abi.h -- C ABI of libgradtts_gfx950.so, the MI355X-native Grad-TTS / DiffVC decoder sampling path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI of its own: its hot path is
+ * Python calling torch ops.  Each entry point below therefore names the reference *Python* symbol it
+ * replaces; the Python host (the modules under speech-backbones_amd/model/) keeps that symbol's signature and calls these
+ * functions through ctypes.  INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch types.  All tensors are fp32, contiguous, row-major, in the
+ *     reference's own layouts ([B,80,T] mels, [B,1,T] masks flattened to [B,T], NCHW inside).
+ *   - the CALLER owns every device buffer (inputs, outputs, packed weights, workspace); the library never
+ *     allocates device memory and keeps no device pointer after a call returns.
+ *   - every call enqueues on the given hipStream_t and returns without synchronising.
+ *   - every function returns 0 on success or a negative GTTS_E_* code; gtts_last_error() gives the text
+ *     (thread-local).  No C++ exception crosses the boundary.
+ *   - T (frames) must be a multiple of 4 (Grad-TTS/model/utils.py:13-17 fix_len_compatibility), n_feats a
+ *     multiple of 4.
+ */
+#ifndef GRADTTS_ABI_H
+#define GRADTTS_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GTTS_ABI_VERSION 1
+
+enum {
+    GTTS_OK = 0,
+    GTTS_E_NULL = -1,        /* required pointer is NULL                                  */
+    GTTS_E_SHAPE = -2,       /* bad B/T/F (T % 4 != 0, non-positive sizes, ...)           */
+    GTTS_E_CONFIG = -3,      /* unsupported model configuration                           */
+    GTTS_E_HIP = -4,         /* HIP launch / runtime error (text in gtts_last_error)      */
+    GTTS_E_PARAMS = -5,      /* parameter list does not match the plan's state_dict layout */
+    GTTS_E_WORKSPACE = -6    /* workspace too small                                       */
+};
+
+/* precision of the dense contractions (3x3 / 1x1 / transposed convs, attention products) */
+enum {
+    GTTS_PREC_BF16X3 = 0,    /* split-bf16 (hi/lo, 3 MFMAs, fp32 accumulate): fp32-grade accuracy (default) */
+    GTTS_PREC_BF16 = 1       /* single bf16 MFMA, fp32 accumulate (BASELINE.json config 3)                  */
+};
+
+typedef void *gtts_stream_t; /* hipStream_t */
+
+/* Mirrors GradLogPEstimator2d.__init__ (Grad-TTS/model/diffusion.py:129-130) plus Diffusion's betas
+ * (diffusion.py:228-230). */
+typedef struct gtts_unet_cfg {
+    int dim;             /* dec_dim, 64                                      */
+    int n_feats;         /* 80                                               */
+    int n_spks;          /* 1 -> 2 input channels; >1 -> 3 + spk_mlp         */
+    int spk_emb_dim;     /* 64                                               */
+    int groups;          /* GroupNorm groups, 8                              */
+    float pe_scale;      /* 1000                                             */
+    float beta_min;      /* 0.05                                             */
+    float beta_max;      /* 20.0                                             */
+    int precision;       /* GTTS_PREC_*                                      */
+    int keep_intermediates; /* 1: every op output gets its own workspace slot (tests / debugging)       */
+} gtts_unet_cfg;
+
+typedef struct gtts_plan gtts_plan;   /* host-side metadata only */
+
+int gtts_abi_version(void);
+const char *gtts_last_error(void);
+
+/* ---- plan ------------------------------------------------------------------------------------------ */
+int gtts_plan_create(const gtts_unet_cfg *cfg, gtts_plan **out);
+void gtts_plan_destroy(gtts_plan *plan);
+
+/* state_dict layout the plan expects, in the reference's registration order:
+ * name (relative to `estimator.`), rank and dims of parameter i; count via gtts_plan_num_params. */
+int gtts_plan_num_params(const gtts_plan *plan);
+int gtts_plan_param_info(const gtts_plan *plan, int i, const char **name, int *rank, int dims[4]);
+
+size_t gtts_packed_weight_bytes(const gtts_plan *plan);
+size_t gtts_workspace_bytes(const gtts_plan *plan, int B, int T);
+
+/* Re-layout the estimator parameters (device fp32 pointers, in gtts_plan_param_info order) into the packed
+ * blob the kernels read (bf16 hi/lo MFMA fragment order for conv weights, fp32 for the rest).
+ * `freq` = the 32 (dim/2) sinusoidal frequencies exp(-k ln(1e4)/(dim/2-1)) as fp32 device values computed by
+ * the host exactly as SinusoidalPosEmb does (diffusion.py:121-122). */
+int gtts_pack_weights(const gtts_plan *plan, const void *const *param_ptrs, int n_params, const float *freq,
+                      void *packed, gtts_stream_t stream);
+
+/* ---- GradLogPEstimator2d.forward(x, mask, mu, t, spk)  diffusion.py:174-216 -------------------------- */
+/* x, mu, out [B,F,T]; mask [B,T]; t [B]; spk [B,spk_emb_dim] (already embedded) or NULL. */
+int gtts_estimator_forward(const gtts_plan *plan, const void *packed, const float *x, const float *mask,
+                           const float *mu, const float *t, const float *spk, float *out, void *workspace,
+                           size_t workspace_bytes, int B, int T, gtts_stream_t stream);
+
+/* ---- one update of Diffusion.reverse_diffusion  diffusion.py:264-274 --------------------------------- */
+/* xt is updated IN PLACE.  noise == NULL: ODE branch; else SDE branch with the pre-drawn N(0,1) tensor. */
+int gtts_euler_step(float *xt, const float *mu, const float *est, const float *mask, const float *noise,
+                    float beta_t, float h, int B, int F, int T, gtts_stream_t stream);
+
+/* ---- Diffusion.reverse_diffusion / forward  diffusion.py:254-279 (whole N-step loop) ------------------ */
+/* z, mu, out [B,F,T]; mask [B,T]; spk nullable; noise nullable [N,B,F,T] (stoc=True <=> noise != NULL). */
+int gtts_reverse_diffusion(const gtts_plan *plan, const void *packed, const float *z, const float *mask,
+                           const float *mu, const float *spk, const float *noise, float *out, void *workspace,
+                           size_t workspace_bytes, int B, int T, int n_timesteps, gtts_stream_t stream);
+
+/* ---- monotonic_align.maximum_path  monotonic_align/core.pyx:9-45 + __init__.py:8-23 ------------------- */
+/* value [b,tx,ty] fp32 (NOT modified), mask [b,tx,ty] fp32 or NULL, t_x / t_y [b] int32 device arrays,
+ * path [b,tx,ty] int32 (written: 0/1), scratch >= gtts_mas_scratch_bytes(b,tx,ty) device bytes. */
+size_t gtts_mas_scratch_bytes(int b, int tx, int ty);
+int gtts_mas_maximum_path(const float *value, const float *mask, const int *t_x, const int *t_y, int *path,
+                          void *scratch, int b, int tx, int ty, gtts_stream_t stream);
+
+/* ---- debugging / tests: named intermediates of the last estimator call (keep_intermediates plans) ----- */
+int gtts_plan_num_tensors(const gtts_plan *plan);
+/* offset is in bytes into the workspace for the given (B,T); dims = {B,C,H,W}. */
+int gtts_plan_tensor_info(const gtts_plan *plan, int i, int B, int T, const char **name, size_t *offset,
+                          int dims[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRADTTS_ABI_H */

@@ -1,0 +1,246 @@
+"""ctypes binding of libgradtts_gfx950.so (C ABI: include/gradtts_abi.h).
+
+PyTorch is only plumbing here: it owns device memory (packed weights, workspace, tensors) and the stream.
+There is NO fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgradtts_gfx950.so")
+
+PREC_BF16X3 = 0
+PREC_BF16 = 1
+
+_lib = None
+_lock = threading.Lock()
+
+
+class UnetCfg(ctypes.Structure):
+    _fields_ = [("dim", ctypes.c_int), ("n_feats", ctypes.c_int), ("n_spks", ctypes.c_int),
+                ("spk_emb_dim", ctypes.c_int), ("groups", ctypes.c_int), ("pe_scale", ctypes.c_float),
+                ("beta_min", ctypes.c_float), ("beta_max", ctypes.c_float), ("precision", ctypes.c_int),
+                ("keep_intermediates", ctypes.c_int)]
+
+
+def lib():
+    """Load the HIP library (once).  Fails loudly when it has not been built."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libgradtts_gfx950.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `python speech-backbones_amd/build.py`. There is no CPU/PyTorch fallback for the sampling path."
+                % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        vp, i, f, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+        L.gtts_abi_version.restype = i
+        L.gtts_last_error.restype = ctypes.c_char_p
+        L.gtts_plan_create.argtypes = [ctypes.POINTER(UnetCfg), ctypes.POINTER(vp)]
+        L.gtts_plan_destroy.argtypes = [vp]
+        L.gtts_plan_destroy.restype = None
+        L.gtts_plan_num_params.argtypes = [vp]
+        L.gtts_plan_param_info.argtypes = [vp, i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(i),
+                                           ctypes.POINTER(i * 4)]
+        L.gtts_packed_weight_bytes.argtypes = [vp]
+        L.gtts_packed_weight_bytes.restype = sz
+        L.gtts_workspace_bytes.argtypes = [vp, i, i]
+        L.gtts_workspace_bytes.restype = sz
+        L.gtts_pack_weights.argtypes = [vp, ctypes.POINTER(vp), i, vp, vp, vp]
+        L.gtts_estimator_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, vp]
+        L.gtts_euler_step.argtypes = [vp, vp, vp, vp, vp, f, f, i, i, i, vp]
+        L.gtts_reverse_diffusion.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, i, vp]
+        L.gtts_mas_scratch_bytes.argtypes = [i, i, i]
+        L.gtts_mas_scratch_bytes.restype = sz
+        L.gtts_mas_maximum_path.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, vp]
+        L.gtts_plan_num_tensors.argtypes = [vp]
+        L.gtts_plan_tensor_info.argtypes = [vp, i, i, i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz),
+                                            ctypes.POINTER(i * 4)]
+        if L.gtts_abi_version() != 1:
+            raise RuntimeError("libgradtts_gfx950.so ABI version mismatch")
+        _lib = L
+        return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, lib().gtts_last_error().decode()))
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _f32c(t, name):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on a HIP device (got %s); the sampling path has no CPU fallback" %
+                           (name, t.device))
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class Plan:
+    """Host-side plan of one score U-Net (mirrors GradLogPEstimator2d.__init__, diffusion.py:129-172)."""
+
+    def __init__(self, dim=64, n_feats=80, n_spks=1, spk_emb_dim=64, groups=8, pe_scale=1000.0, beta_min=0.05,
+                 beta_max=20.0, precision=PREC_BF16X3, keep_intermediates=False):
+        self.cfg = UnetCfg(int(dim), int(n_feats), int(n_spks), int(spk_emb_dim), int(groups), float(pe_scale),
+                           float(beta_min), float(beta_max), int(precision), 1 if keep_intermediates else 0)
+        self._h = ctypes.c_void_p()
+        _check(lib().gtts_plan_create(ctypes.byref(self.cfg), ctypes.byref(self._h)), "gtts_plan_create")
+        self._ws = {}
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().gtts_plan_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- state_dict layout
+    def param_layout(self):
+        L = lib()
+        out = []
+        for k in range(L.gtts_plan_num_params(self._h)):
+            name, rank, dims = ctypes.c_char_p(), ctypes.c_int(), (ctypes.c_int * 4)()
+            _check(L.gtts_plan_param_info(self._h, k, ctypes.byref(name), ctypes.byref(rank), ctypes.byref(dims)),
+                   "gtts_plan_param_info")
+            out.append((name.value.decode(), tuple(dims[:rank.value])))
+        return out
+
+    def packed_bytes(self):
+        return int(lib().gtts_packed_weight_bytes(self._h))
+
+    def workspace_bytes(self, B, T):
+        n = int(lib().gtts_workspace_bytes(self._h, int(B), int(T)))
+        if n == 0:
+            raise RuntimeError("gtts_workspace_bytes: %s" % lib().gtts_last_error().decode())
+        return n
+
+    def workspace(self, B, T, device):
+        key = (int(B), int(T), str(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            self._ws.clear()      # one shape at a time: the caching allocator recycles the old block
+            ws = torch.empty(self.workspace_bytes(B, T), dtype=torch.uint8, device=device)
+            self._ws[key] = ws
+        return ws
+
+    # ---- weights
+    def pack(self, state, device):
+        """state: mapping name -> tensor with the estimator-level names of the reference state_dict."""
+        layout = self.param_layout()
+        keep = []
+        for name, shape in layout:
+            if name not in state:
+                raise RuntimeError("state_dict is missing '%s'" % name)
+            t = state[name].detach().to(device=device, dtype=torch.float32).contiguous()
+            if tuple(t.shape) != shape:
+                raise RuntimeError("parameter %s has shape %s, expected %s" % (name, tuple(t.shape), shape))
+            keep.append(t)
+        arr = (ctypes.c_void_p * len(keep))(*[t.data_ptr() for t in keep])
+        half = self.cfg.dim // 2
+        # exactly SinusoidalPosEmb's frequency table, computed on the host CPU like the reference (diffusion.py:121-122)
+        import math
+        freq = torch.exp(torch.arange(half).float() * -(math.log(10000) / (half - 1))).to(device)
+        blob = torch.empty(self.packed_bytes(), dtype=torch.uint8, device=device)
+        with torch.cuda.device(blob.device):
+            _check(lib().gtts_pack_weights(self._h, arr, len(keep), _ptr(freq), _ptr(blob), _stream()),
+                   "gtts_pack_weights")
+            torch.cuda.current_stream().synchronize()     # sources in `keep` may be temporaries
+        return blob
+
+    # ---- GradLogPEstimator2d.forward
+    def estimator_forward(self, blob, x, mask, mu, t, spk=None):
+        x, mask, mu, t, spk = (_f32c(x, "x"), _f32c(mask, "mask"), _f32c(mu, "mu"), _f32c(t, "t"),
+                               _f32c(spk, "spk"))
+        B, F, T = x.shape
+        if F != self.cfg.n_feats:
+            raise RuntimeError("expected %d mel bins, got %d" % (self.cfg.n_feats, F))
+        if mask.numel() != B * T or mu.shape != x.shape or t.numel() != B:
+            raise RuntimeError("shape mismatch: x %s mask %s mu %s t %s" % (tuple(x.shape), tuple(mask.shape),
+                                                                         tuple(mu.shape), tuple(t.shape)))
+        out = torch.empty_like(x)
+        ws = self.workspace(B, T, x.device)
+        with torch.cuda.device(x.device):
+            _check(lib().gtts_estimator_forward(self._h, _ptr(blob), _ptr(x), _ptr(mask), _ptr(mu), _ptr(t), _ptr(spk),
+                                                _ptr(out), _ptr(ws), ws.numel(), B, T, _stream()),
+                   "gtts_estimator_forward")
+        return out
+
+    # ---- Diffusion.reverse_diffusion (whole loop)
+    def reverse_diffusion(self, blob, z, mask, mu, n_timesteps, spk=None, noise=None):
+        z, mask, mu, spk, noise = (_f32c(z, "z"), _f32c(mask, "mask"), _f32c(mu, "mu"), _f32c(spk, "spk"),
+                                   _f32c(noise, "noise"))
+        B, F, T = z.shape
+        if F != self.cfg.n_feats:
+            raise RuntimeError("expected %d mel bins, got %d" % (self.cfg.n_feats, F))
+        if mask.numel() != B * T or mu.shape != z.shape:
+            raise RuntimeError("shape mismatch: z %s mask %s mu %s" % (tuple(z.shape), tuple(mask.shape), tuple(mu.shape)))
+        if noise is not None and tuple(noise.shape) != (int(n_timesteps), B, F, T):
+            raise RuntimeError("noise must be [n_timesteps, B, F, T]")
+        out = torch.empty_like(z)
+        ws = self.workspace(B, T, z.device)
+        with torch.cuda.device(z.device):
+            _check(lib().gtts_reverse_diffusion(self._h, _ptr(blob), _ptr(z), _ptr(mask), _ptr(mu), _ptr(spk),
+                                                _ptr(noise), _ptr(out), _ptr(ws), ws.numel(), B, T, int(n_timesteps),
+                                                _stream()), "gtts_reverse_diffusion")
+        return out
+
+    # ---- debugging: named intermediates (keep_intermediates plans)
+    def tensors(self, B, T, device):
+        L = lib()
+        ws = self.workspace(B, T, device)
+        out = {}
+        for k in range(L.gtts_plan_num_tensors(self._h)):
+            name, off, dims = ctypes.c_char_p(), ctypes.c_size_t(), (ctypes.c_int * 4)()
+            _check(L.gtts_plan_tensor_info(self._h, k, int(B), int(T), ctypes.byref(name), ctypes.byref(off),
+                                           ctypes.byref(dims)), "gtts_plan_tensor_info")
+            n = dims[0] * dims[1] * dims[2] * dims[3]
+            if n <= 0:
+                continue
+            view = ws[off.value: off.value + 4 * n].view(torch.float32).view(*dims)
+            out[name.value.decode()] = view
+        return out
+
+
+def euler_step(xt, mu, est, mask, beta_t, h, noise=None):
+    """In-place update of xt (one step of Diffusion.reverse_diffusion, diffusion.py:264-274)."""
+    if not xt.is_cuda or xt.dtype != torch.float32 or not xt.is_contiguous():
+        raise RuntimeError("xt must be a contiguous fp32 HIP tensor (updated in place)")
+    mu, est, mask, noise = _f32c(mu, "mu"), _f32c(est, "est"), _f32c(mask, "mask"), _f32c(noise, "noise")
+    B, F, T = xt.shape
+    with torch.cuda.device(xt.device):
+        _check(lib().gtts_euler_step(_ptr(xt), _ptr(mu), _ptr(est), _ptr(mask), _ptr(noise), float(beta_t), float(h),
+                                     B, F, T, _stream()), "gtts_euler_step")
+    return xt
+
+
+def mas_maximum_path(value, mask):
+    """monotonic_align.maximum_path(value, mask) on the GPU (value, mask: [b, t_x, t_y] HIP tensors)."""
+    if not value.is_cuda:
+        raise RuntimeError("value must live on a HIP device; the GPU MAS kernel has no CPU fallback")
+    v = value.detach().float().contiguous()
+    m = mask.detach().to(device=v.device, dtype=torch.float32).contiguous()
+    b, tx, ty = v.shape
+    t_x = m.sum(1)[:, 0].to(torch.int32).contiguous()       # __init__.py:20-21
+    t_y = m.sum(2)[:, 0].to(torch.int32).contiguous()
+    path = torch.empty((b, tx, ty), dtype=torch.int32, device=v.device)
+    scratch = torch.empty(int(lib().gtts_mas_scratch_bytes(b, tx, ty)), dtype=torch.uint8, device=v.device)
+    with torch.cuda.device(v.device):
+        _check(lib().gtts_mas_maximum_path(_ptr(v), _ptr(m), _ptr(t_x), _ptr(t_y), _ptr(path), _ptr(scratch), b, tx,
+                                           ty, _stream()), "gtts_mas_maximum_path")
+    return path.to(dtype=value.dtype)

@@ -1,0 +1,308 @@
+// attn.hip -- LinearAttention (Grad-TTS/model/diffusion.py:82-100, wrapped by Rezero :39-46 and Residual
+// :103-110) restructured for gfx950 so that q/k/v are never materialised in HBM.
+//
+// Reference:  qkv = to_qkv(x); k = softmax_n(k); ctx[h][d][e] = sum_n k[d,n] v[e,n];
+//             out[h][e][n] = sum_d ctx[d][e] q[d,n];  y = to_out(out) + b;  result = y * g + x
+// Algebra:    q = Wq x is linear, so   y[:, n] = (Wout . blockdiag_h(ctx_h^T) . Wq) x[:, n] + b = M_b x[:, n] + b
+//             with one C x C matrix M_b per sample.  Hence:
+//   pass 1  attn_ctx    per (sample, head, pixel slice): k,v = Wkv_h x on the MFMA pipe, flash-style online
+//                       softmax over n (running max m, normaliser Z) and ctx += P V^T on the MFMA pipe with
+//                       the projection's own accumulator registers as operands (no LDS transpose: the
+//                       k-slot <-> pixel mapping of the C/D layout is identical for P and V).
+//           attn_merge  log-sum-exp merge of the per-wave partials -> normalised ctx[b][h][32][32]
+//           attn_fold   M_b = g * Wout . blockdiag(ctx^T) . Wq (fp32 VALU, tiny), written straight into the
+//                       packed bf16 hi/lo layout of the 1x1 MFMA convolution; bias_b = g * b
+//   pass 2  conv_mfma CONV_P1 with per-sample weights and EPI_ATTN (+ x): reads x once, writes once.
+// Softmax quirks kept: over ALL h*w positions, no mask, no 1/sqrt(d) scaling, q not normalised.
+#include "common.h"
+#include "kernels.h"
+
+namespace gtts {
+
+struct AttnCtxArgs {
+    const float *x;
+    const unsigned char *wkv;
+    float *partials;
+    int C, HW, nstage, tiles, tps, nrec, nsplit;
+};
+
+__device__ __forceinline__ void pack8_split(const float (&v)[8], u32x4 &hi, u32x4 &lo) {
+    bf16x8 vh, vl;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        __bf16 h, l;
+        split_bf16(v[i], h, l);
+        vh[i] = h;
+        vl[i] = l;
+    }
+    hi = *reinterpret_cast<u32x4 *>(&vh);
+    lo = *reinterpret_cast<u32x4 *>(&vl);
+}
+
+__global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
+    constexpr int KCH = ATTN_KCH, NKG = 2 * KCH;
+    __shared__ __attribute__((aligned(16))) u32x4 s_ah[NKG * 256];
+    __shared__ __attribute__((aligned(16))) u32x4 s_al[NKG * 256];
+    __shared__ __attribute__((aligned(16))) u32x4 s_w[2 * NKG * 64];     // [split][kg][64 rows: k_h(32) | v_h(32)]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kgl = lane >> 5;
+    const int slice = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const int tile0 = slice * a.tps;
+    const int tile1 = min(tile0 + a.tps, a.tiles);
+    const float *xb = a.x + (size_t)b * a.C * a.HW;
+    const u32x4 *wblk = reinterpret_cast<const u32x4 *>(a.wkv) + (size_t)head * a.nstage * (2 * NKG * 64);
+
+    float raw[NKG][8];
+    u32x4 wregs[KCH];
+    auto load = [&](int tile, int stage) {
+        const int n = tile * 256 + tid;
+        const bool nv = n < a.HW;
+#pragma unroll
+        for (int kg = 0; kg < NKG; ++kg) {
+            const int cb = stage * 16 * KCH + kg * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool ok = nv && (cb + i) < a.C;
+                raw[kg][i] = ok ? xb[(size_t)(cb + i) * a.HW + n] : 0.f;
+            }
+        }
+        const u32x4 *g = wblk + (size_t)stage * (2 * NKG * 64);
+#pragma unroll
+        for (int j = 0; j < KCH; ++j) wregs[j] = g[tid + j * 256];
+    };
+
+    const float NEG_INF = -__builtin_inff();
+    float m_run = NEG_INF, z_run = 0.f;
+    f32x16 ctx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
+    const bool lo_on = a.nsplit > 1;
+
+    load(tile0, 0);
+    for (int tile = tile0; tile < tile1; ++tile) {
+        f32x16 acc[2][2];     // [pixel fragment][0: k_h, 1: v_h]; D' layout: col = channel, rows = pixels
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
+            for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[pf][cf][r] = 0.f;
+
+        for (int stage = 0; stage < a.nstage; ++stage) {
+            __syncthreads();
+#pragma unroll
+            for (int kg = 0; kg < NKG; ++kg) {
+                u32x4 hi, lo;
+                pack8_split(raw[kg], hi, lo);
+                s_ah[kg * 256 + tid] = hi;
+                s_al[kg * 256 + tid] = lo;
+            }
+#pragma unroll
+            for (int j = 0; j < KCH; ++j) s_w[tid + j * 256] = wregs[j];
+            __syncthreads();
+            if (stage + 1 < a.nstage) load(tile, stage + 1);
+            else if (tile + 1 < tile1) load(tile + 1, 0);
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc) {
+                bf16x8 xh[2], xl[2], wh[2], wl[2];
+#pragma unroll
+                for (int pf = 0; pf < 2; ++pf) {
+                    const int xi = (kc * 2 + kgl) * 256 + wave * 64 + pf * 32 + l31;
+                    xh[pf] = *reinterpret_cast<const bf16x8 *>(&s_ah[xi]);
+                    xl[pf] = *reinterpret_cast<const bf16x8 *>(&s_al[xi]);
+                }
+#pragma unroll
+                for (int cf = 0; cf < 2; ++cf) {
+                    const int wi = (kc * 2 + kgl) * 64 + cf * 32 + l31;
+                    wh[cf] = *reinterpret_cast<const bf16x8 *>(&s_w[wi]);
+                    wl[cf] = *reinterpret_cast<const bf16x8 *>(&s_w[wi + NKG * 64]);
+                }
+#pragma unroll
+                for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
+                    for (int cf = 0; cf < 2; ++cf) {
+                        if (lo_on) {
+                            acc[pf][cf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[pf], wh[cf], acc[pf][cf], 0, 0, 0);
+                            acc[pf][cf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[pf], wl[cf], acc[pf][cf], 0, 0, 0);
+                        }
+                        acc[pf][cf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[pf], wh[cf], acc[pf][cf], 0, 0, 0);
+                    }
+            }
+        }
+
+        // ---- online softmax over this wave's 64 pixels: lane (l31, kgl) owns channel d = l31 (k) / e = l31 (v)
+        const int nbase = tile * 256 + wave * 64 + 4 * kgl;
+        float tmax = NEG_INF;
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) {
+                const int n = nbase + pf * 32 + (rg & 3) + 8 * (rg >> 2);
+                if (n < a.HW) tmax = fmaxf(tmax, acc[pf][0][rg]);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = (m_run == NEG_INF) ? 0.f : __expf(m_run - m_new);
+        const float msub = (m_new == NEG_INF) ? 0.f : m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) {
+                const int n = nbase + pf * 32 + (rg & 3) + 8 * (rg >> 2);
+                const float p = (n < a.HW) ? __expf(acc[pf][0][rg] - msub) : 0.f;
+                acc[pf][0][rg] = p;
+                psum += p;
+            }
+        psum += __shfl_xor(psum, 32, 64);
+        z_run = z_run * alpha + psum;
+        m_run = m_new;
+        // ctx rows are d = (rg&3) + 8*(rg>>2) + 4*kgl: fetch that channel's rescale factor from lane d
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+            const int d = (rg & 3) + 8 * (rg >> 2) + 4 * kgl;
+            ctx[rg] *= __shfl(alpha, d, 64);
+        }
+        // ctx[d][e] += sum_n p[d,n] v[e,n]: A = P (i = d), B = V (n = e); the k-slot (lane>>5, j) maps to the
+        // same pixel in both operands because both come from the same C/D register layout.
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                float pv[8], vv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    pv[i] = acc[pf][0][hh * 8 + i];
+                    vv[i] = acc[pf][1][hh * 8 + i];
+                }
+                u32x4 ph, pl, vh, vl;
+                pack8_split(pv, ph, pl);
+                pack8_split(vv, vh, vl);
+                const bf16x8 Ph = *reinterpret_cast<bf16x8 *>(&ph), Pl = *reinterpret_cast<bf16x8 *>(&pl);
+                const bf16x8 Vh = *reinterpret_cast<bf16x8 *>(&vh), Vl = *reinterpret_cast<bf16x8 *>(&vl);
+                if (lo_on) {
+                    ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Pl, Vh, ctx, 0, 0, 0);
+                    ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ph, Vl, ctx, 0, 0, 0);
+                }
+                ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ph, Vh, ctx, 0, 0, 0);
+            }
+    }
+
+    // ---- per-wave partial record: m[32], Z[32], ctx[32][32] (relative to m)
+    float *rec = a.partials + ((((size_t)b * 4 + head) * a.nrec) + (size_t)slice * 4 + wave) * ATTN_REC;
+    if (kgl == 0) {
+        rec[l31] = m_run;
+        rec[32 + l31] = z_run;
+    }
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+        const int d = (rg & 3) + 8 * (rg >> 2) + 4 * kgl;
+        rec[64 + d * 32 + l31] = ctx[rg];
+    }
+}
+
+hipError_t launch_attn_ctx(const float *x, const unsigned char *wkv, float *partials, int B, int C, int HW, int nsplit,
+                           hipStream_t st) {
+    AttnGeom g = attn_geom(HW);
+    AttnCtxArgs a;
+    a.x = x; a.wkv = wkv; a.partials = partials; a.C = C; a.HW = HW;
+    a.nstage = (C + 16 * ATTN_KCH - 1) / (16 * ATTN_KCH);
+    a.tiles = g.tiles; a.tps = g.tps; a.nrec = g.nrec; a.nsplit = nsplit;
+    hipLaunchKernelGGL(attn_ctx_kernel, dim3(g.nslices, 4, B), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ attn_merge
+// grid (4 heads, B).  ctxn[b][h][d][e] = sum_i ctx_i[d][e] exp(m_i[d]-M[d]) / sum_i Z_i[d] exp(m_i[d]-M[d])
+__global__ void attn_merge_kernel(const float *__restrict__ partials, float *__restrict__ ctxn, int nrec) {
+    __shared__ float s_M[32], s_Zi[32];
+    const int head = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float *rec = partials + ((size_t)b * 4 + head) * nrec * ATTN_REC;
+    const float NEG_INF = -__builtin_inff();
+    if (tid < 32) {
+        float M = NEG_INF;
+        for (int i = 0; i < nrec; ++i) M = fmaxf(M, rec[(size_t)i * ATTN_REC + tid]);
+        float Z = 0.f;
+        for (int i = 0; i < nrec; ++i) {
+            const float mi = rec[(size_t)i * ATTN_REC + tid];
+            if (mi != NEG_INF) Z += rec[(size_t)i * ATTN_REC + 32 + tid] * expf(mi - M);
+        }
+        s_M[tid] = M;
+        s_Zi[tid] = 1.0f / Z;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 1024; idx += 256) {
+        const int d = idx >> 5;
+        const float M = s_M[d];
+        float acc = 0.f;
+        for (int i = 0; i < nrec; ++i) {
+            const float mi = rec[(size_t)i * ATTN_REC + d];
+            if (mi != NEG_INF) acc += rec[(size_t)i * ATTN_REC + 64 + idx] * expf(mi - M);
+        }
+        ctxn[(((size_t)b * 4 + head) * 1024) + idx] = acc * s_Zi[d];
+    }
+}
+
+hipError_t launch_attn_merge(const float *partials, float *ctxn, int B, int nrec, hipStream_t st) {
+    hipLaunchKernelGGL(attn_merge_kernel, dim3(4, B), dim3(256), 0, st, partials, ctxn, nrec);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ attn_fold
+// grid (C/16, B).  M[co][ci] = g * sum_{h,d} U[co][h,d] Wq[h*32+d][ci],  U[co][h,d] = sum_e Wout[co][h*32+e] ctx_h[d][e]
+__global__ void attn_fold_kernel(const float *__restrict__ ctxn, const float *__restrict__ wq,
+                                 const float *__restrict__ wout, const float *__restrict__ bout,
+                                 const float *__restrict__ g, unsigned char *__restrict__ wpk, size_t wpk_bstride,
+                                 float *__restrict__ biasb, int C, int MT) {
+    __shared__ float s_U[16][128];
+    const int co0 = blockIdx.x * 16, b = blockIdx.y, tid = threadIdx.x;
+    const float *cb = ctxn + (size_t)b * 4096;
+    for (int idx = tid; idx < 16 * 128; idx += 256) {
+        const int r = idx >> 7, j = idx & 127, h = j >> 5, d = j & 31;
+        const float *wo = wout + (size_t)(co0 + r) * 128 + h * 32;
+        const float *cx = cb + (h * 32 + d) * 32;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int e = 0; e < 32; ++e) acc = fmaf(wo[e], cx[e], acc);
+        s_U[r][j] = acc;
+    }
+    __syncthreads();
+    const float gv = g[0];
+    const int ncot = (C + MT - 1) / MT;
+    __bf16 *wp = reinterpret_cast<__bf16 *>(wpk + (size_t)b * wpk_bstride);
+    for (int ci = tid; ci < C; ci += 256) {
+        float acc[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int j = 0; j < 128; ++j) {
+            const float q = wq[(size_t)j * C + ci];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = fmaf(s_U[r][j], q, acc[r]);
+        }
+        const int chunk = ci >> 4, kg = (ci >> 3) & 1, i = ci & 7;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + r, cot = co / MT, m = co % MT;
+            const size_t blk = (size_t)chunk * ncot + cot;             // CONV_P1: one stage, one tap
+            const size_t e_hi = blk * ((size_t)MT * 32) + ((size_t)(0 * 2 + kg) * MT + m) * 8 + i;
+            const size_t e_lo = blk * ((size_t)MT * 32) + ((size_t)(1 * 2 + kg) * MT + m) * 8 + i;
+            __bf16 hi, lo;
+            split_bf16(acc[r] * gv, hi, lo);
+            wp[e_hi] = hi;
+            wp[e_lo] = lo;
+        }
+    }
+    if (tid < 16) biasb[(size_t)b * C + co0 + tid] = gv * bout[co0 + tid];
+}
+
+hipError_t launch_attn_fold(const float *ctxn, const float *wq, const float *wout, const float *bout, const float *g,
+                            unsigned char *wpk, size_t wpk_bstride, float *biasb, int B, int C, hipStream_t st) {
+    if (C % 16 != 0) return hipErrorInvalidValue;
+    ConvGeom geom = conv_geom(CONV_P1, C);
+    hipLaunchKernelGGL(attn_fold_kernel, dim3(C / 16, B), dim3(256), 0, st, ctxn, wq, wout, bout, g, wpk, wpk_bstride,
+                       biasb, C, geom.MT);
+    return hipGetLastError();
+}
+
+}  // namespace gtts

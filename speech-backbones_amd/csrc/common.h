@@ -1,0 +1,119 @@
+// common.h -- shared device helpers and host-side launch descriptors (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace gtts {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // 16-byte LDS / global unit
+
+// ---------------------------------------------------------------------------------------------------
+// Mish(x) = x * tanh(softplus(x)),  torch softplus: x > 20 -> x         (Grad-TTS/model/diffusion.py:16-18)
+// tanh(log(1+e^x)) = ((1+e^x)^2 - 1) / ((1+e^x)^2 + 1) = n / (n + 2),  n = e^x (e^x + 2): one exp, one rcp,
+// no cancellation for very negative x (n -> 2 e^x).  For x > 20 tanh(softplus) == 1 in fp32.
+__device__ __forceinline__ float mish_f(float x) {
+    float e = __expf(fminf(x, 20.0f));
+    float n = e * (e + 2.0f);
+    float r = n * __builtin_amdgcn_rcpf(n + 2.0f);
+    return x > 20.0f ? x : x * r;
+}
+
+// fp32 -> (hi, lo) bf16 pair with hi + lo == x to ~2^-17 relative (both round-to-nearest-even).
+__device__ __forceinline__ void split_bf16(float x, __bf16 &h, __bf16 &l) {
+    h = (__bf16)x;
+    l = (__bf16)(x - (float)h);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// MFMA convolution launch descriptor (conv_mfma.hip).  One kernel family covers the 3x3 Block convs, the
+// stride-2 Downsample, the 4x4/stride-2 ConvTranspose (as four 2x2 phase convs), and every 1x1 conv.
+enum ConvMode { CONV_C3 = 0, CONV_DN = 1, CONV_UP = 2, CONV_P1 = 3 };
+enum ConvPro {
+    PRO_PLAIN = 0,   // v = x
+    PRO_MASK = 1,    // v = x * mask                                   (Block input,    diffusion.py:57)
+    PRO_GN = 2       // v = (Mish(GN(x)) * mask + tbias) * mask        (block1 -> block2, diffusion.py:58,76,57)
+};
+enum ConvEpi {
+    EPI_PLAIN = 0,   // out = acc + bias
+    EPI_STATS = 1,   // out = acc + bias, plus per-(sample,group) partial sums for GroupNorm
+    EPI_TAIL = 2,    // out = acc + bias + Mish(GN(h_raw)) * mask      (ResnetBlock tail with res_conv, :78)
+    EPI_ATTN = 3     // out = acc + bias_b + x                          (Residual(Rezero(LinearAttention)))
+};
+
+struct ConvArgs {
+    // input: channels [0,c0) come from src0, [c0,c0+c1) from src1 (torch.cat on dim 1 without the copy)
+    const float *src0;
+    const float *src1;
+    int c0, c1;
+    int cin;            // c0 + c1
+    int nchunk;         // ceil(cin / 16)
+    int B, Hin, Win, Hout, Wout;
+    const float *mask;  // [B][T] (level-0 mask); level-l column j is mask[b][j << lvl]
+    int T;
+    int lvl_in, lvl_out;
+    int pro;
+    const float *sc, *sh;   // PRO_GN: per-(b, input channel) GroupNorm scale / shift   [B][cin]
+    const float *tb;        // PRO_GN: per-(b, input channel) time bias, row stride tb_stride (pre-offset)
+    int tb_stride;
+    // weights: packed bf16 blocks (see pack.hip); per-sample stride in bytes (0 = shared)
+    const unsigned char *w;
+    size_t w_bstride;
+    const float *bias;      // [cout] (+ b * bias_bstride floats)
+    size_t bias_bstride;
+    int cout;
+    int epi;
+    float *out;             // [B][cout][Hout][Wout]
+    float *partials;        // EPI_STATS: [B][nparts][groups][2]
+    int nparts;
+    int groups;
+    const float *eh;        // EPI_TAIL: h_raw [B][cout][Hout][Wout]
+    const float *esc, *esh; // EPI_TAIL: [B][cout]
+    const float *eres;      // EPI_ATTN: residual [B][cout][Hout][Wout]
+    int nsplit;             // 2: bf16x3 (hi/lo), 1: plain bf16
+    int tiles_x, tiles_y;
+};
+
+// geometry of one conv configuration (compile-time in the kernel, mirrored on the host)
+struct ConvGeom {
+    int MT;     // output channels per workgroup
+    int TR;     // output rows per workgroup (32 columns always)
+    int nst;    // weight stages per 16-channel chunk
+    int tps;    // taps per stage
+};
+// host helper: how a layer is tiled (must match the template instantiations in conv_mfma.hip)
+static inline ConvGeom conv_geom(int mode, int cout) {
+    ConvGeom g;
+    bool wide = cout > 64;
+    g.MT = wide ? 128 : 64;
+    if (mode == CONV_DN) { g.TR = 4; g.nst = 3; g.tps = 3; }
+    else if (mode == CONV_UP) { g.TR = wide ? 4 : 8; g.nst = 2; g.tps = 2; }
+    else if (mode == CONV_P1) { g.TR = wide ? 4 : 8; g.nst = 1; g.tps = 1; }
+    else { g.TR = wide ? 4 : 8; g.nst = 3; g.tps = 3; }
+    return g;
+}
+static inline size_t conv_wblock_bytes(const ConvGeom &g) { return (size_t)g.tps * g.MT * 64; }
+// packed bytes of one conv's weights: [phase][chunk][stage][cout tile] blocks
+static inline size_t conv_packed_bytes(int mode, int cin, int cout) {
+    ConvGeom g = conv_geom(mode, cout);
+    size_t nchunk = (cin + 15) / 16, ncot = (cout + g.MT - 1) / g.MT;
+    size_t phases = (mode == CONV_UP) ? 4 : 1;
+    return phases * nchunk * g.nst * ncot * conv_wblock_bytes(g);
+}
+
+hipError_t launch_conv(int mode, const ConvArgs &a, hipStream_t st);
+
+}  // namespace gtts

@@ -1,0 +1,77 @@
+// kernels.h -- host-visible launchers of every kernel in libgradtts_gfx950 (internal header).
+#pragma once
+#include "common.h"
+
+namespace gtts {
+
+// ---- misc.hip
+struct TimeMlpDesc {
+    int dim;                 // time embedding width (dec_dim)
+    size_t w0, b0, w2, b2;   // blob byte offsets of mlp.0 / mlp.2 (fp32, reference layout [out][in])
+    int n;                   // number of ResnetBlocks
+    int cout[32];
+    size_t w[32], b[32];     // blob byte offsets of <R>.mlp.1.{weight,bias}
+    int off[32];             // column of the block's bias vector inside a tb row
+    int temb_off;            // column where the raw time embedding (dim floats) is stored
+    int tb_stride;
+};
+
+hipError_t launch_prep_input(const float *mu, const float *x, const float *s, float *x0, int B, int F, int T,
+                             int nch, hipStream_t st);
+hipError_t launch_spk_mlp(const float *spk, const float *w0, const float *b0, const float *w2, const float *b2,
+                          float *s, int B, int E, int F, hipStream_t st);
+hipError_t launch_time_mlp(const float *t, const float *freq, float pe_scale, const unsigned char *blob,
+                           const TimeMlpDesc &d, float *tb, int rows, hipStream_t st);
+hipError_t launch_gn_finalize(const float *partials, int nparts, int groups, int C, int HW, const float *gamma,
+                              const float *beta, float *sc, float *sh, int B, hipStream_t st);
+hipError_t launch_tail_identity(const float *h, const float *x, const float *sc, const float *sh, const float *mask,
+                                float *out, int B, int C, int H, int W, int T, int lvl, hipStream_t st);
+hipError_t launch_euler_step(float *xt, const float *mu, const float *est, const float *mask, const float *noise,
+                             float beta, float h, int B, int F, int T, hipStream_t st);
+hipError_t launch_mul_mask(const float *z, const float *mask, float *out, int B, int F, int T, hipStream_t st);
+hipError_t launch_final_euler(const float *raw, const float *sc, const float *sh, const float *w, const float *bias,
+                              const float *mask, int B, int C, int F, int T, float *est_out, float *xt, const float *mu,
+                              const float *noise, float beta, float h, hipStream_t st);
+
+// ---- conv_mfma.hip
+int conv_nparts(int mode, int cout, int Hout, int Wout);
+
+// ---- attn.hip  (LinearAttention, diffusion.py:82-100, folded: see attn.hip header)
+constexpr int ATTN_KCH = 2;                 // 16-channel chunks per LDS stage of the k/v projection
+constexpr int ATTN_REC = 32 + 32 + 32 * 32; // floats per partial record: m[32], Z[32], ctx[32][32]
+struct AttnGeom {
+    int tiles;          // 256-pixel tiles per sample
+    int tps;            // tiles per slice (one workgroup walks a slice)
+    int nslices;
+    int nrec;           // partial records per (sample, head) = nslices * 4 waves
+};
+static inline AttnGeom attn_geom(int HW) {
+    AttnGeom g;
+    g.tiles = (HW + 255) / 256;
+    int t = g.tiles / 16;
+    g.tps = t < 1 ? 1 : (t > 16 ? 16 : t);
+    g.nslices = (g.tiles + g.tps - 1) / g.tps;
+    g.nrec = g.nslices * 4;
+    return g;
+}
+static inline size_t attn_kv_packed_bytes(int C) {      // [head 4][stage][split 2][kg 2*KCH][64][8] bf16
+    size_t nstage = (C + 16 * ATTN_KCH - 1) / (16 * ATTN_KCH);
+    return 4 * nstage * 2 * (2 * ATTN_KCH) * 64 * 16;
+}
+hipError_t launch_attn_ctx(const float *x, const unsigned char *wkv, float *partials, int B, int C, int HW, int nsplit,
+                           hipStream_t st);
+hipError_t launch_attn_merge(const float *partials, float *ctxn, int B, int nrec, hipStream_t st);
+// wq [128][C], wout [C][128], bout [C], g [1] fp32 (reference layouts) -> per-sample packed 1x1 weights + bias
+hipError_t launch_attn_fold(const float *ctxn, const float *wq, const float *wout, const float *bout, const float *g,
+                            unsigned char *wpk, size_t wpk_bstride, float *biasb, int B, int C, hipStream_t st);
+
+// ---- pack.hip
+hipError_t launch_pack_conv(int mode, const float *w, unsigned char *dst, int cin, int cout, hipStream_t st);
+hipError_t launch_pack_attn_kv(const float *wqkv, unsigned char *dst, int C, hipStream_t st);
+hipError_t launch_copy_f32(const float *src, float *dst, size_t n, hipStream_t st);
+
+// ---- mas.hip
+hipError_t launch_mas(const float *value, const float *mask, const int *t_x, const int *t_y, int *path,
+                      unsigned char *scratch, int b, int tx, int ty, hipStream_t st);
+
+}  // namespace gtts

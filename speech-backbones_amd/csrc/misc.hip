@@ -1,0 +1,287 @@
+// misc.hip -- the bandwidth-bound and tiny kernels around the MFMA convolutions (gfx950).
+//   prep_input      torch.stack([mu, x(, s)], 1)                       diffusion.py:181-185
+//   spk_mlp         spk_mlp(spk)                                       diffusion.py:139-141,176
+//   time_mlp        SinusoidalPosEmb -> mlp -> per-ResnetBlock Linear(Mish(t))   diffusion.py:118-125,143-144,64-65,76
+//   gn_finalize     GroupNorm statistics -> per-(sample, channel) scale/shift    diffusion.py:53 (eps 1e-5, biased var)
+//   tail_identity   ResnetBlock tail with Identity res_conv: Mish(GN(h))*mask + x*mask   diffusion.py:58,72,78
+//   final_euler     final_block GN/Mish/mask + final_conv 1x1 + mask (+ Euler update)    diffusion.py:213-216,264-274
+//   euler_step      one reverse-diffusion update                                          diffusion.py:264-274
+#include "common.h"
+#include "kernels.h"
+
+namespace gtts {
+
+// ------------------------------------------------------------------------------------------------ prep_input
+__global__ void prep_input_kernel(const float *__restrict__ mu, const float *__restrict__ x,
+                                  const float *__restrict__ s, float *__restrict__ x0, int F, int T, int nch) {
+    // grid: (ceil(F*T/256), nch, B)
+    const int b = blockIdx.z, c = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= F * T) return;
+    float v;
+    if (c == 0) v = mu[(size_t)b * F * T + i];
+    else if (c == 1) v = x[(size_t)b * F * T + i];
+    else v = s[(size_t)b * F + i / T];     // speaker channel: constant along frames (diffusion.py:184)
+    x0[((size_t)b * nch + c) * F * T + i] = v;
+}
+
+hipError_t launch_prep_input(const float *mu, const float *x, const float *s, float *x0, int B, int F, int T,
+                             int nch, hipStream_t st) {
+    dim3 grid((F * T + 255) / 256, nch, B);
+    hipLaunchKernelGGL(prep_input_kernel, grid, dim3(256), 0, st, mu, x, s, x0, F, T, nch);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ small MLPs
+__device__ __forceinline__ float dot_row(const float *__restrict__ w, const float *v, int n) {
+    float acc = 0.f;
+    for (int i = 0; i < n; ++i) acc = fmaf(w[i], v[i], acc);
+    return acc;
+}
+
+// spk_mlp: Linear(E -> 4E) -> Mish -> Linear(4E -> F);   one workgroup per sample
+__global__ void spk_mlp_kernel(const float *__restrict__ spk, const float *__restrict__ w0,
+                               const float *__restrict__ b0, const float *__restrict__ w2,
+                               const float *__restrict__ b2, float *__restrict__ s, int E, int F) {
+    extern __shared__ float sm[];
+    float *e = sm, *h = sm + E;
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < E; i += blockDim.x) e[i] = spk[(size_t)b * E + i];
+    __syncthreads();
+    for (int j = threadIdx.x; j < 4 * E; j += blockDim.x) h[j] = mish_f(b0[j] + dot_row(w0 + (size_t)j * E, e, E));
+    __syncthreads();
+    for (int j = threadIdx.x; j < F; j += blockDim.x) s[(size_t)b * F + j] = b2[j] + dot_row(w2 + (size_t)j * 4 * E, h, 4 * E);
+}
+
+hipError_t launch_spk_mlp(const float *spk, const float *w0, const float *b0, const float *w2, const float *b2,
+                          float *s, int B, int E, int F, hipStream_t st) {
+    hipLaunchKernelGGL(spk_mlp_kernel, dim3(B), dim3(256), (size_t)5 * E * sizeof(float), st, spk, w0, b0, w2, b2, s,
+                       E, F);
+    return hipGetLastError();
+}
+
+// time_mlp: one workgroup per (step, sample) row.  freq[] is computed on the host exactly as the reference does
+// (torch.exp(arange(half).float() * -log(1e4)/(half-1)) on CPU), so the sin/cos arguments are bit-identical.
+__global__ void time_mlp_kernel(const float *__restrict__ t, const float *__restrict__ freq, float pe_scale,
+                                const unsigned char *__restrict__ blob, TimeMlpDesc d, float *__restrict__ tb) {
+    extern __shared__ float sm[];
+    const int dim = d.dim, half = dim / 2;
+    float *emb = sm, *h = sm + dim, *t2 = h + 4 * dim;
+    const int row = blockIdx.x;
+    const float tv = t[row];
+    for (int k = threadIdx.x; k < half; k += blockDim.x) {
+        const float arg = __fmul_rn(__fmul_rn(pe_scale, tv), freq[k]);   // scale * x * emb  (diffusion.py:123)
+        emb[k] = sinf(arg);
+        emb[half + k] = cosf(arg);
+    }
+    __syncthreads();
+    const float *w0 = reinterpret_cast<const float *>(blob + d.w0), *b0 = reinterpret_cast<const float *>(blob + d.b0);
+    const float *w2 = reinterpret_cast<const float *>(blob + d.w2), *b2 = reinterpret_cast<const float *>(blob + d.b2);
+    for (int j = threadIdx.x; j < 4 * dim; j += blockDim.x) h[j] = mish_f(b0[j] + dot_row(w0 + (size_t)j * dim, emb, dim));
+    __syncthreads();
+    for (int j = threadIdx.x; j < dim; j += blockDim.x) {
+        const float v = b2[j] + dot_row(w2 + (size_t)j * 4 * dim, h, 4 * dim);
+        t2[j] = v;
+        tb[(size_t)row * d.tb_stride + d.temb_off + j] = v;    // raw time embedding (DiffVC RefBlock / tests)
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < dim; j += blockDim.x) emb[j] = mish_f(t2[j]);   // Mish() of ResnetBlock.mlp
+    __syncthreads();
+    for (int r = 0; r < d.n; ++r) {
+        const float *w = reinterpret_cast<const float *>(blob + d.w[r]);
+        const float *bb = reinterpret_cast<const float *>(blob + d.b[r]);
+        for (int co = threadIdx.x; co < d.cout[r]; co += blockDim.x)
+            tb[(size_t)row * d.tb_stride + d.off[r] + co] = bb[co] + dot_row(w + (size_t)co * dim, emb, dim);
+    }
+}
+
+hipError_t launch_time_mlp(const float *t, const float *freq, float pe_scale, const unsigned char *blob,
+                           const TimeMlpDesc &d, float *tb, int rows, hipStream_t st) {
+    hipLaunchKernelGGL(time_mlp_kernel, dim3(rows), dim3(256), (size_t)6 * d.dim * sizeof(float), st, t, freq,
+                       pe_scale, blob, d, tb);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ gn_finalize
+// partials [B][nparts][groups][2] (fp32 sums of x and x^2 per workgroup tile, fixed order) ->
+// scale[b][c] = gamma[c] * rstd,  shift[b][c] = beta[c] - mean * scale.   One workgroup per sample, 32 lanes per
+// group, double accumulation, fixed reduction order => bit-reproducible run to run.
+__global__ void gn_finalize_kernel(const float *__restrict__ partials, int nparts, int groups, int C, float count,
+                                   const float *__restrict__ gamma, const float *__restrict__ beta,
+                                   float *__restrict__ sc, float *__restrict__ sh) {
+    const int b = blockIdx.x;
+    const int g = threadIdx.x >> 5, l = threadIdx.x & 31;
+    if (g >= groups) return;
+    double s1 = 0.0, s2 = 0.0;
+    const float *p = partials + (size_t)b * nparts * groups * 2;
+    for (int i = l; i < nparts; i += 32) {
+        s1 += (double)p[((size_t)i * groups + g) * 2 + 0];
+        s2 += (double)p[((size_t)i * groups + g) * 2 + 1];
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 32);
+        s2 += __shfl_xor(s2, o, 32);
+    }
+    const double mean = s1 / (double)count;
+    double var = s2 / (double)count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + 1e-5);
+    const int gs = C / groups;
+    for (int c = g * gs + l; c < (g + 1) * gs; c += 32) {
+        const double a = (double)gamma[c] * rstd;
+        sc[(size_t)b * C + c] = (float)a;
+        sh[(size_t)b * C + c] = (float)((double)beta[c] - mean * a);
+    }
+}
+
+hipError_t launch_gn_finalize(const float *partials, int nparts, int groups, int C, int HW, const float *gamma,
+                              const float *beta, float *sc, float *sh, int B, hipStream_t st) {
+    if (groups * 32 > 1024) return hipErrorInvalidValue;
+    const float count = (float)((double)(C / groups) * (double)HW);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(groups * 32), 0, st, partials, nparts, groups, C, count,
+                       gamma, beta, sc, sh);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ tail_identity
+template <int VEC>
+__global__ void tail_identity_kernel(const float *__restrict__ h, const float *__restrict__ x,
+                                     const float *__restrict__ sc, const float *__restrict__ sh,
+                                     const float *__restrict__ mask, float *__restrict__ out, int C, int H, int W,
+                                     int T, int lvl) {
+    // grid: (ceil(H*W/VEC/256), C, B): one (sample, channel) plane per blockIdx.(y,z) -> scalar scale/shift
+    const int b = blockIdx.z, c = blockIdx.y;
+    const int i = (blockIdx.x * 256 + threadIdx.x) * VEC;
+    if (i >= H * W) return;
+    const float a = sc[(size_t)b * C + c], s = sh[(size_t)b * C + c];
+    const size_t base = ((size_t)b * C + c) * H * W + i;
+    const int col = i % W;
+    if (VEC == 4) {
+        const float4 hv = *reinterpret_cast<const float4 *>(h + base);
+        const float4 xv = *reinterpret_cast<const float4 *>(x + base);
+        const float *mp = mask + (size_t)b * T;
+        const float m0 = mp[(size_t)(col + 0) << lvl], m1 = mp[(size_t)(col + 1) << lvl];
+        const float m2 = mp[(size_t)(col + 2) << lvl], m3 = mp[(size_t)(col + 3) << lvl];
+        float4 o;
+        o.x = mish_f(hv.x * a + s) * m0 + xv.x * m0;
+        o.y = mish_f(hv.y * a + s) * m1 + xv.y * m1;
+        o.z = mish_f(hv.z * a + s) * m2 + xv.z * m2;
+        o.w = mish_f(hv.w * a + s) * m3 + xv.w * m3;
+        *reinterpret_cast<float4 *>(out + base) = o;
+    } else {
+        const float m = mask[(size_t)b * T + ((size_t)col << lvl)];
+        out[base] = mish_f(h[base] * a + s) * m + x[base] * m;
+    }
+}
+
+hipError_t launch_tail_identity(const float *h, const float *x, const float *sc, const float *sh, const float *mask,
+                                float *out, int B, int C, int H, int W, int T, int lvl, hipStream_t st) {
+    if (W % 4 == 0) {
+        dim3 grid((H * W / 4 + 255) / 256, C, B);
+        hipLaunchKernelGGL(tail_identity_kernel<4>, grid, dim3(256), 0, st, h, x, sc, sh, mask, out, C, H, W, T, lvl);
+    } else {
+        dim3 grid((H * W + 255) / 256, C, B);
+        hipLaunchKernelGGL(tail_identity_kernel<1>, grid, dim3(256), 0, st, h, x, sc, sh, mask, out, C, H, W, T, lvl);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ Euler update
+// Exactly the reference's fp32 operation order (diffusion.py:264-274); explicit *_rn intrinsics forbid FMA
+// contraction so that, given the same estimator output, the update is bit-identical to the CPU path.
+__device__ __forceinline__ float euler_update(float xt, float mu, float est, float m, float noise, bool stoc,
+                                              float beta, float h, float sq) {
+    float dxt;
+    if (stoc) {
+        float det = __fsub_rn(__fmul_rn(0.5f, __fsub_rn(mu, xt)), est);      // 0.5*(mu - xt) - est
+        det = __fmul_rn(__fmul_rn(det, beta), h);                            // * noise_t * h
+        dxt = __fadd_rn(det, __fmul_rn(noise, sq));                          // + randn * sqrt(noise_t*h)
+    } else {
+        dxt = __fmul_rn(0.5f, __fsub_rn(__fsub_rn(mu, xt), est));            // 0.5*(mu - xt - est)
+        dxt = __fmul_rn(__fmul_rn(dxt, beta), h);
+    }
+    return __fmul_rn(__fsub_rn(xt, dxt), m);                                 // (xt - dxt) * mask
+}
+
+__global__ void euler_step_kernel(float *__restrict__ xt, const float *__restrict__ mu,
+                                  const float *__restrict__ est, const float *__restrict__ mask,
+                                  const float *__restrict__ noise, float beta, float h, float sq, int F, int T,
+                                  size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int col = (int)(i % T);
+    const size_t b = i / ((size_t)F * T);
+    const float m = mask[b * T + col];
+    xt[i] = euler_update(xt[i], mu[i], est[i], m, noise ? noise[i] : 0.f, noise != nullptr, beta, h, sq);
+}
+
+hipError_t launch_euler_step(float *xt, const float *mu, const float *est, const float *mask, const float *noise,
+                             float beta, float h, int B, int F, int T, hipStream_t st) {
+    const size_t total = (size_t)B * F * T;
+    const float sq = sqrtf(beta * h);     // torch.sqrt(noise_t * h) in fp32
+    hipLaunchKernelGGL(euler_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, xt, mu, est, mask,
+                       noise, beta, h, sq, F, T, total);
+    return hipGetLastError();
+}
+
+__global__ void mul_mask_kernel(const float *__restrict__ z, const float *__restrict__ mask, float *__restrict__ out,
+                                int F, int T, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int col = (int)(i % T);
+    const size_t b = i / ((size_t)F * T);
+    out[i] = __fmul_rn(z[i], mask[b * T + col]);
+}
+
+hipError_t launch_mul_mask(const float *z, const float *mask, float *out, int B, int F, int T, hipStream_t st) {
+    const size_t total = (size_t)B * F * T;
+    hipLaunchKernelGGL(mul_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, z, mask, out, F, T,
+                       total);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ final_euler
+// est = (sum_c w[c] * (Mish(GN(raw[c])) * m) * m + bias) * m        (final_block :56-58, final_conv :214-216)
+// then optionally the Euler update of xt in the same pass (est never touches HBM inside the sampling loop).
+__global__ void final_euler_kernel(const float *__restrict__ raw, const float *__restrict__ sc,
+                                   const float *__restrict__ sh, const float *__restrict__ w, const float *__restrict__ bias,
+                                   const float *__restrict__ mask, int C, int F, int T, float *__restrict__ est_out,
+                                   float *__restrict__ xt, const float *__restrict__ mu, const float *__restrict__ noise,
+                                   float beta, float h, float sq) {
+    extern __shared__ float sm[];     // [3][C]: scale, shift, weight
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < C; i += 256) {
+        sm[i] = sc[(size_t)b * C + i];
+        sm[C + i] = sh[(size_t)b * C + i];
+        sm[2 * C + i] = w[i];
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int FT = F * T;
+    if (i >= FT) return;
+    const int col = i % T;
+    const float m = mask[(size_t)b * T + col];
+    const float *p = raw + (size_t)b * C * FT + i;
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float v = mish_f(p[(size_t)c * FT] * sm[c] + sm[C + c]) * m * m;
+        acc = fmaf(sm[2 * C + c], v, acc);
+    }
+    const float est = (acc + bias[0]) * m;
+    const size_t o = (size_t)b * FT + i;
+    if (est_out) est_out[o] = est;
+    if (xt) xt[o] = euler_update(xt[o], mu[o], est, m, noise ? noise[o] : 0.f, noise != nullptr, beta, h, sq);
+}
+
+hipError_t launch_final_euler(const float *raw, const float *sc, const float *sh, const float *w, const float *bias,
+                              const float *mask, int B, int C, int F, int T, float *est_out, float *xt, const float *mu,
+                              const float *noise, float beta, float h, hipStream_t st) {
+    dim3 grid((F * T + 255) / 256, B);
+    const float sq = sqrtf(beta * h);
+    hipLaunchKernelGGL(final_euler_kernel, grid, dim3(256), (size_t)3 * C * sizeof(float), st, raw, sc, sh, w, bias,
+                       mask, C, F, T, est_out, xt, mu, noise, beta, h, sq);
+    return hipGetLastError();
+}
+
+}  // namespace gtts

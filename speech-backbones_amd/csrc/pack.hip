@@ -1,0 +1,106 @@
+// pack.hip -- one-time re-layout of the estimator parameters into the packed blob (device side).
+//
+// Convolution weights become bf16 (hi, lo) pairs in MFMA-fragment order, one contiguous block per
+// (phase, 16-channel chunk, stage, cout tile); inside a block the order is the LDS image of conv_mfma.hip:
+//     [split: hi|lo][tap][kgroup 0|1][cout-in-tile MT][8 channels]
+// Source layouts are the reference's state_dict layouts:
+//   Conv2d          [cout][cin][kh][kw]        (diffusion.py:33,52,70,87-88)
+//   ConvTranspose2d [cin][cout][4][4]          (diffusion.py:24)
+#include "common.h"
+#include "kernels.h"
+
+namespace gtts {
+
+__global__ void pack_conv_kernel(const float *__restrict__ w, __bf16 *__restrict__ dst, int mode, int cin, int cout,
+                                 int MT, int nst, int tps, int nchunk, int ncot, size_t total) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;   // one thread per (hi, lo) element pair
+    if (t >= total) return;
+    // decode t -> (phase, chunk, stage, cot, tap, kg, m, i)
+    size_t r = t;
+    const int i = r % 8; r /= 8;
+    const int m = r % MT; r /= MT;
+    const int kg = r % 2; r /= 2;
+    const int tap = r % tps; r /= tps;
+    const int cot = r % ncot; r /= ncot;
+    const int stage = r % nst; r /= nst;
+    const int chunk = r % nchunk; r /= nchunk;
+    const int phase = (int)r;
+    const int ci = chunk * 16 + kg * 8 + i;
+    const int co = cot * MT + m;
+    float v = 0.f;
+    if (ci < cin && co < cout) {
+        if (mode == CONV_C3 || mode == CONV_DN) {
+            v = w[(((size_t)co * cin + ci) * 3 + stage) * 3 + tap];          // ky = stage, kx = tap
+        } else if (mode == CONV_P1) {
+            v = w[(size_t)co * cin + ci];
+        } else {   // CONV_UP: output phase (py, px); stage/tap pick the two contributing kernel rows/cols
+            const int py = phase >> 1, px = phase & 1;
+            const int ky = py == 0 ? (stage == 0 ? 1 : 3) : (stage == 0 ? 0 : 2);
+            const int kx = px == 0 ? (tap == 0 ? 1 : 3) : (tap == 0 ? 0 : 2);
+            v = w[(((size_t)ci * cout + co) * 4 + ky) * 4 + kx];
+        }
+    }
+    __bf16 hi, lo;
+    split_bf16(v, hi, lo);
+    const size_t blk = (((size_t)phase * nchunk + chunk) * nst + stage) * ncot + cot;
+    const size_t blk_elems = (size_t)tps * MT * 32;                          // bf16 elements per block
+    const size_t e_hi = blk * blk_elems + (((size_t)(0 * tps + tap) * 2 + kg) * MT + m) * 8 + i;
+    const size_t e_lo = blk * blk_elems + (((size_t)(1 * tps + tap) * 2 + kg) * MT + m) * 8 + i;
+    dst[e_hi] = hi;
+    dst[e_lo] = lo;
+}
+
+hipError_t launch_pack_conv(int mode, const float *w, unsigned char *dst, int cin, int cout, hipStream_t st) {
+    ConvGeom g = conv_geom(mode, cout);
+    const int nchunk = (cin + 15) / 16, ncot = (cout + g.MT - 1) / g.MT;
+    const int phases = mode == CONV_UP ? 4 : 1;
+    const size_t total = (size_t)phases * nchunk * g.nst * ncot * g.tps * 2 * g.MT * 8;
+    hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w,
+                       reinterpret_cast<__bf16 *>(dst), mode, cin, cout, g.MT, g.nst, g.tps, nchunk, ncot, total);
+    return hipGetLastError();
+}
+
+// to_qkv.weight [384][C] (channel order (qkv, heads, c), diffusion.py:93-94) -> per-head k|v projection blocks
+//   [head 4][stage][split][kg 2*KCH][row 64: k_h d=0..31 | v_h e=0..31][8 channels]
+__global__ void pack_attn_kv_kernel(const float *__restrict__ wqkv, __bf16 *__restrict__ dst, int C, int nstage,
+                                    size_t total) {
+    constexpr int NKG = 2 * ATTN_KCH;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    size_t r = t;
+    const int i = r % 8; r /= 8;
+    const int row = r % 64; r /= 64;
+    const int kg = r % NKG; r /= NKG;
+    const int stage = r % nstage; r /= nstage;
+    const int head = (int)r;
+    const int ci = stage * 16 * ATTN_KCH + kg * 8 + i;
+    const int src_row = row < 32 ? 128 + head * 32 + row : 256 + head * 32 + (row - 32);
+    const float v = ci < C ? wqkv[(size_t)src_row * C + ci] : 0.f;
+    __bf16 hi, lo;
+    split_bf16(v, hi, lo);
+    const size_t blk = (size_t)head * nstage + stage;
+    const size_t blk_elems = (size_t)2 * NKG * 64 * 8;
+    dst[blk * blk_elems + (((size_t)0 * NKG + kg) * 64 + row) * 8 + i] = hi;
+    dst[blk * blk_elems + (((size_t)1 * NKG + kg) * 64 + row) * 8 + i] = lo;
+}
+
+hipError_t launch_pack_attn_kv(const float *wqkv, unsigned char *dst, int C, hipStream_t st) {
+    const int nstage = (C + 16 * ATTN_KCH - 1) / (16 * ATTN_KCH);
+    const size_t total = (size_t)4 * nstage * (2 * ATTN_KCH) * 64 * 8;
+    hipLaunchKernelGGL(pack_attn_kv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, wqkv,
+                       reinterpret_cast<__bf16 *>(dst), C, nstage, total);
+    return hipGetLastError();
+}
+
+__global__ void copy_f32_kernel(const float *__restrict__ src, float *__restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+hipError_t launch_copy_f32(const float *src, float *dst, size_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(copy_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
+    return hipGetLastError();
+}
+
+}  // namespace gtts

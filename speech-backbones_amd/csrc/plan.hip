@@ -1,0 +1,762 @@
+// plan.hip -- host side of libgradtts_gfx950: the plan (state_dict layout, packed-weight layout, op program,
+// workspace allocation) and the extern "C" entry points declared in include/gradtts_abi.h.
+//
+// The plan is pure host metadata.  Every device byte belongs to the caller (packed blob, workspace, tensors);
+// every call just enqueues kernels on the caller's stream.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/gradtts_abi.h"
+#include "common.h"
+#include "kernels.h"
+
+using namespace gtts;
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                                        \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) return fail(GTTS_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                          __FILE__, __LINE__);                                              \
+    } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ------------------------------------------------------------------------------------------------ plan data
+enum TensorKind { TK_ACT, TK_PERB, TK_PART, TK_APART, TK_BYTES_PERB, TK_ROWS };
+struct Tensor {
+    std::string name;
+    int kind;
+    int C;          // TK_ACT: channels; TK_PERB: floats per sample; TK_BYTES_PERB: bytes per sample (in `bytes`)
+    int lvl;        // resolution level of a TK_ACT / TK_PART / TK_APART tensor
+    size_t bytes;   // TK_BYTES_PERB
+    int mode, cout; // TK_PART: conv geometry that produces it
+    bool external;  // not in the workspace (inputs / outputs of the call)
+    int first, last;
+};
+
+enum OpKind { OP_CONV, OP_GNFIN, OP_TAILID, OP_ACTX, OP_AMERGE, OP_AFOLD };
+struct Op {
+    int kind;
+    // conv
+    int mode, pro, epi;
+    int src0, src1, c0, c1, cout, lvl_in, lvl_out;
+    int sc, sh, tb_off;            // PRO_GN inputs (tensor ids) and column inside the tb row
+    size_t w_off, b_off;           // blob offsets (shared weights) ...
+    int w_t, bias_t;               // ... or per-sample tensors (attention pass 2), -1 if unused
+    int out, part, eh, esc, esh, eres;
+    // gn finalize
+    int C;
+    size_t gamma_off, beta_off;
+    // attention
+    size_t wkv_off, wq_off, wout_off, bout_off, g_off;
+    int apart, ctxn;
+    std::string label;
+};
+
+struct ParamDesc {
+    std::string name;
+    int rank;
+    int dims[4];
+    size_t off;      // blob byte offset of the packed / copied form
+    int pack;        // 0 copy fp32, 1 conv C3, 2 conv DN, 3 conv UP, 4 conv P1, 5 to_qkv (kv packed + q copy)
+    size_t off2;     // to_qkv: fp32 copy of the q rows
+    int cin, cout;
+};
+
+struct gtts_plan {
+    gtts_unet_cfg cfg;
+    int cin0;
+    int nlev;
+    int dims[4];
+    std::vector<ParamDesc> params;
+    std::map<std::string, int> pidx;
+    size_t blob_bytes;
+    size_t freq_off;
+    TimeMlpDesc tmlp;
+    size_t spk_w0, spk_b0, spk_w2, spk_b2;
+    std::vector<Tensor> tensors;
+    std::vector<Op> ops;
+    int t_x0, t_s, t_tb, t_final_raw, t_final_sc, t_final_sh;
+    size_t fw_off, fb_off;     // final_conv weight / bias (fp32)
+    // workspace layout cache
+    int cache_B = -1, cache_T = -1;
+    std::vector<size_t> offsets;
+    size_t ws_bytes = 0;
+};
+
+// ------------------------------------------------------------------------------------------------ builders
+static int add_param(gtts_plan *p, const std::string &name, std::vector<int> dims, int pack, int cin = 0, int cout = 0) {
+    ParamDesc d;
+    d.name = name;
+    d.rank = (int)dims.size();
+    for (int i = 0; i < 4; ++i) d.dims[i] = i < (int)dims.size() ? dims[i] : 1;
+    d.pack = pack;
+    d.cin = cin;
+    d.cout = cout;
+    d.off = p->blob_bytes;
+    d.off2 = 0;
+    size_t bytes = 0;
+    size_t n = 1;
+    for (int v : dims) n *= (size_t)v;
+    switch (pack) {
+        case 0: bytes = n * 4; break;
+        case 1: bytes = conv_packed_bytes(CONV_C3, cin, cout); break;
+        case 2: bytes = conv_packed_bytes(CONV_DN, cin, cout); break;
+        case 3: bytes = conv_packed_bytes(CONV_UP, cin, cout); break;
+        case 4: bytes = conv_packed_bytes(CONV_P1, cin, cout); break;
+        case 5: bytes = attn_kv_packed_bytes(cin); break;
+    }
+    p->blob_bytes = align_up(p->blob_bytes + bytes, 256);
+    if (pack == 5) {
+        d.off2 = p->blob_bytes;
+        p->blob_bytes = align_up(p->blob_bytes + (size_t)128 * cin * 4, 256);
+    }
+    p->pidx[name] = (int)p->params.size();
+    p->params.push_back(d);
+    return (int)p->params.size() - 1;
+}
+static size_t poff(const gtts_plan *p, const std::string &name) { return p->params[p->pidx.at(name)].off; }
+
+static int add_tensor(gtts_plan *p, const std::string &name, int kind, int C, int lvl, bool external = false) {
+    Tensor t;
+    t.name = name; t.kind = kind; t.C = C; t.lvl = lvl; t.bytes = 0; t.mode = 0; t.cout = 0;
+    t.external = external; t.first = 1 << 30; t.last = -1;
+    p->tensors.push_back(t);
+    return (int)p->tensors.size() - 1;
+}
+
+static Op blank_op(int kind, const std::string &label) {
+    Op o;
+    o.kind = kind; o.mode = 0; o.pro = 0; o.epi = 0; o.src0 = o.src1 = -1; o.c0 = o.c1 = 0; o.cout = 0;
+    o.lvl_in = o.lvl_out = 0; o.sc = o.sh = -1; o.tb_off = 0; o.w_off = o.b_off = 0; o.w_t = o.bias_t = -1;
+    o.out = o.part = o.eh = o.esc = o.esh = o.eres = -1; o.C = 0; o.gamma_off = o.beta_off = 0;
+    o.wkv_off = o.wq_off = o.wout_off = o.bout_off = o.g_off = 0; o.apart = o.ctxn = -1;
+    o.label = label;
+    return o;
+}
+
+// Block: conv3x3 (+stats) and the GroupNorm finalize.  Returns raw / sc / sh tensor ids.
+static void add_block(gtts_plan *p, const std::string &pre, const std::string &tname, int src0, int c0, int src1,
+                      int c1, int cout, int lvl, int pro, int psc, int psh, int tb_off, int *raw, int *sc, int *sh) {
+    const int cin = c0 + c1;
+    add_param(p, pre + "block.0.weight", {cout, cin, 3, 3}, 1, cin, cout);
+    add_param(p, pre + "block.0.bias", {cout}, 0);
+    add_param(p, pre + "block.1.weight", {cout}, 0);
+    add_param(p, pre + "block.1.bias", {cout}, 0);
+    *raw = add_tensor(p, tname + ".raw", TK_ACT, cout, lvl);
+    int part = add_tensor(p, tname + ".part", TK_PART, p->cfg.groups, lvl);
+    p->tensors[part].mode = CONV_C3;
+    p->tensors[part].cout = cout;
+    *sc = add_tensor(p, tname + ".sc", TK_PERB, cout, 0);
+    *sh = add_tensor(p, tname + ".sh", TK_PERB, cout, 0);
+    Op c = blank_op(OP_CONV, tname + ".conv");
+    c.mode = CONV_C3; c.pro = pro; c.epi = EPI_STATS;
+    c.src0 = src0; c.src1 = src1; c.c0 = c0; c.c1 = c1; c.cout = cout; c.lvl_in = c.lvl_out = lvl;
+    c.sc = psc; c.sh = psh; c.tb_off = tb_off;
+    c.w_off = poff(p, pre + "block.0.weight");
+    c.b_off = poff(p, pre + "block.0.bias");
+    c.out = *raw; c.part = part;
+    p->ops.push_back(c);
+    Op g = blank_op(OP_GNFIN, tname + ".gn");
+    g.part = part; g.C = cout; g.lvl_in = lvl;
+    g.gamma_off = poff(p, pre + "block.1.weight");
+    g.beta_off = poff(p, pre + "block.1.bias");
+    g.sc = *sc; g.sh = *sh;
+    p->ops.push_back(g);
+}
+
+// ResnetBlock (diffusion.py:61-79).  Input = cat(src0[c0], src1[c1]); returns the output tensor id.
+static int add_resnet(gtts_plan *p, const std::string &name, int src0, int c0, int src1, int c1, int cout, int lvl) {
+    const int cin = c0 + c1, dim = p->cfg.dim;
+    const std::string pre = name + ".";
+    // registration order inside ResnetBlock: mlp, block1, block2, res_conv
+    add_param(p, pre + "mlp.1.weight", {cout, dim}, 0);
+    add_param(p, pre + "mlp.1.bias", {cout}, 0);
+    TimeMlpDesc &tm = p->tmlp;
+    const int r = tm.n++;
+    tm.cout[r] = cout;
+    tm.w[r] = poff(p, pre + "mlp.1.weight");
+    tm.b[r] = poff(p, pre + "mlp.1.bias");
+    tm.off[r] = r == 0 ? 0 : tm.off[r - 1] + tm.cout[r - 1];
+    int raw1, sc1, sh1, raw2, sc2, sh2;
+    add_block(p, pre + "block1.", name + ".b1", src0, c0, src1, c1, cout, lvl, PRO_MASK, -1, -1, 0, &raw1, &sc1, &sh1);
+    add_block(p, pre + "block2.", name + ".b2", raw1, cout, -1, 0, cout, lvl, PRO_GN, sc1, sh1, tm.off[r], &raw2, &sc2,
+              &sh2);
+    const int out = add_tensor(p, name + ".out", TK_ACT, cout, lvl);
+    if (cin != cout) {
+        add_param(p, pre + "res_conv.weight", {cout, cin, 1, 1}, 4, cin, cout);
+        add_param(p, pre + "res_conv.bias", {cout}, 0);
+        Op c = blank_op(OP_CONV, name + ".res_tail");
+        c.mode = CONV_P1; c.pro = PRO_MASK; c.epi = EPI_TAIL;
+        c.src0 = src0; c.src1 = src1; c.c0 = c0; c.c1 = c1; c.cout = cout; c.lvl_in = c.lvl_out = lvl;
+        c.w_off = poff(p, pre + "res_conv.weight");
+        c.b_off = poff(p, pre + "res_conv.bias");
+        c.out = out; c.eh = raw2; c.esc = sc2; c.esh = sh2;
+        p->ops.push_back(c);
+    } else {
+        Op t = blank_op(OP_TAILID, name + ".tail");
+        t.src0 = src0; t.eh = raw2; t.esc = sc2; t.esh = sh2; t.out = out; t.C = cout; t.lvl_in = lvl;
+        p->ops.push_back(t);
+    }
+    return out;
+}
+
+// Residual(Rezero(LinearAttention)) (diffusion.py:82-110)
+static int add_attn(gtts_plan *p, const std::string &name, int src, int C, int lvl) {
+    const std::string pre = name + ".";
+    add_param(p, pre + "fn.g", {1}, 0);
+    add_param(p, pre + "fn.fn.to_qkv.weight", {384, C, 1, 1}, 5, C, 384);
+    add_param(p, pre + "fn.fn.to_out.weight", {C, 128, 1, 1}, 0);
+    add_param(p, pre + "fn.fn.to_out.bias", {C}, 0);
+    const int apart = add_tensor(p, name + ".apart", TK_APART, 0, lvl);
+    const int ctxn = add_tensor(p, name + ".ctx", TK_PERB, 4096, 0);
+    const int wpk = add_tensor(p, name + ".wfold", TK_BYTES_PERB, 0, 0);
+    p->tensors[wpk].bytes = align_up(conv_packed_bytes(CONV_P1, C, C), 256);
+    const int biasb = add_tensor(p, name + ".bfold", TK_PERB, C, 0);
+    const int out = add_tensor(p, name + ".out", TK_ACT, C, lvl);
+    const ParamDesc &qkv = p->params[p->pidx.at(pre + "fn.fn.to_qkv.weight")];
+    Op a = blank_op(OP_ACTX, name + ".ctx");
+    a.src0 = src; a.C = C; a.lvl_in = lvl; a.wkv_off = qkv.off; a.apart = apart;
+    p->ops.push_back(a);
+    Op m = blank_op(OP_AMERGE, name + ".merge");
+    m.apart = apart; m.ctxn = ctxn; m.lvl_in = lvl;
+    p->ops.push_back(m);
+    Op f = blank_op(OP_AFOLD, name + ".fold");
+    f.ctxn = ctxn; f.C = C; f.wq_off = qkv.off2; f.wout_off = poff(p, pre + "fn.fn.to_out.weight");
+    f.bout_off = poff(p, pre + "fn.fn.to_out.bias"); f.g_off = poff(p, pre + "fn.g");
+    f.w_t = wpk; f.bias_t = biasb;
+    p->ops.push_back(f);
+    Op c = blank_op(OP_CONV, name + ".apply");
+    c.mode = CONV_P1; c.pro = PRO_PLAIN; c.epi = EPI_ATTN;
+    c.src0 = src; c.c0 = C; c.cout = C; c.lvl_in = c.lvl_out = lvl;
+    c.w_t = wpk; c.bias_t = biasb; c.out = out; c.eres = src;
+    p->ops.push_back(c);
+    return out;
+}
+
+static int add_resample(gtts_plan *p, const std::string &name, int src, int C, int lvl, bool down) {
+    const std::string pre = name + ".";
+    if (down) add_param(p, pre + "conv.weight", {C, C, 3, 3}, 2, C, C);
+    else add_param(p, pre + "conv.weight", {C, C, 4, 4}, 3, C, C);
+    add_param(p, pre + "conv.bias", {C}, 0);
+    const int lvl_out = down ? lvl + 1 : lvl - 1;
+    const int out = add_tensor(p, name + ".out", TK_ACT, C, lvl_out);
+    Op c = blank_op(OP_CONV, name);
+    c.mode = down ? CONV_DN : CONV_UP; c.pro = PRO_MASK; c.epi = EPI_PLAIN;
+    c.src0 = src; c.c0 = C; c.cout = C; c.lvl_in = lvl; c.lvl_out = lvl_out;
+    c.w_off = poff(p, pre + "conv.weight"); c.b_off = poff(p, pre + "conv.bias"); c.out = out;
+    p->ops.push_back(c);
+    return out;
+}
+
+static void compute_liveness(gtts_plan *p) {
+    auto touch = [&](int t, int i) {
+        if (t < 0) return;
+        p->tensors[t].first = std::min(p->tensors[t].first, i);
+        p->tensors[t].last = std::max(p->tensors[t].last, i);
+    };
+    for (int i = 0; i < (int)p->ops.size(); ++i) {
+        const Op &o = p->ops[i];
+        const int ids[] = {o.src0, o.src1, o.sc, o.sh, o.w_t, o.bias_t, o.out, o.part, o.eh, o.esc, o.esh, o.eres,
+                           o.apart, o.ctxn};
+        for (int t : ids) touch(t, i);
+    }
+    const int n = (int)p->ops.size();
+    // tensors used outside the op program: alive for the whole call
+    for (int t : {p->t_x0, p->t_s, p->t_tb, p->t_final_raw, p->t_final_sc, p->t_final_sh}) {
+        if (t < 0) continue;
+        p->tensors[t].first = -1;
+        p->tensors[t].last = n + 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI: plan
+extern "C" int gtts_abi_version(void) { return GTTS_ABI_VERSION; }
+extern "C" const char *gtts_last_error(void) { return g_err.c_str(); }
+
+extern "C" int gtts_plan_create(const gtts_unet_cfg *cfg, gtts_plan **out) {
+    if (!cfg || !out) return fail(GTTS_E_NULL, "gtts_plan_create: null argument");
+    if (cfg->dim <= 0 || cfg->dim % 32 != 0) return fail(GTTS_E_CONFIG, "dim must be a positive multiple of 32 (got %d)", cfg->dim);
+    if (cfg->n_feats <= 0 || cfg->n_feats % 4 != 0) return fail(GTTS_E_CONFIG, "n_feats must be a multiple of 4 (got %d)", cfg->n_feats);
+    if (cfg->groups != 8) return fail(GTTS_E_CONFIG, "only groups == 8 is supported (got %d)", cfg->groups);
+    if (cfg->precision != GTTS_PREC_BF16X3 && cfg->precision != GTTS_PREC_BF16) return fail(GTTS_E_CONFIG, "unknown precision %d", cfg->precision);
+    if (cfg->n_spks < 1) return fail(GTTS_E_CONFIG, "n_spks must be >= 1");
+    gtts_plan *p = new gtts_plan();
+    p->cfg = *cfg;
+    p->blob_bytes = 0;
+    p->nlev = 3;
+    const int dim = cfg->dim;
+    const bool multi = cfg->n_spks > 1;
+    p->cin0 = 2 + (multi ? 1 : 0);
+    p->dims[0] = p->cin0; p->dims[1] = dim; p->dims[2] = 2 * dim; p->dims[3] = 4 * dim;
+    memset(&p->tmlp, 0, sizeof(p->tmlp));
+    p->tmlp.dim = dim;
+
+    // blob: frequencies first
+    p->freq_off = p->blob_bytes;
+    p->blob_bytes = align_up(p->blob_bytes + (size_t)(dim / 2) * 4, 256);
+    // ---- parameters in the reference's registration order (diffusion.py:139-172)
+    if (multi) {
+        const int E = cfg->spk_emb_dim;
+        add_param(p, "spk_mlp.0.weight", {4 * E, E}, 0);
+        add_param(p, "spk_mlp.0.bias", {4 * E}, 0);
+        add_param(p, "spk_mlp.2.weight", {cfg->n_feats, 4 * E}, 0);
+        add_param(p, "spk_mlp.2.bias", {cfg->n_feats}, 0);
+        p->spk_w0 = poff(p, "spk_mlp.0.weight"); p->spk_b0 = poff(p, "spk_mlp.0.bias");
+        p->spk_w2 = poff(p, "spk_mlp.2.weight"); p->spk_b2 = poff(p, "spk_mlp.2.bias");
+    }
+    add_param(p, "mlp.0.weight", {4 * dim, dim}, 0);
+    add_param(p, "mlp.0.bias", {4 * dim}, 0);
+    add_param(p, "mlp.2.weight", {dim, 4 * dim}, 0);
+    add_param(p, "mlp.2.bias", {dim}, 0);
+    p->tmlp.w0 = poff(p, "mlp.0.weight"); p->tmlp.b0 = poff(p, "mlp.0.bias");
+    p->tmlp.w2 = poff(p, "mlp.2.weight"); p->tmlp.b2 = poff(p, "mlp.2.bias");
+
+    p->t_x0 = add_tensor(p, "x0", TK_ACT, p->cin0, 0);
+    p->t_s = multi ? add_tensor(p, "spk_s", TK_PERB, cfg->n_feats, 0) : -1;
+    p->t_tb = add_tensor(p, "tb", TK_ROWS, 0, 0);
+
+    // The U-Net is *executed* downs -> mid -> ups -> final, but `ups` is registered before `mid_*`
+    // (diffusion.py:148-149: the empty ModuleList is created first).  Parameter order below follows execution;
+    // gtts_plan_param_info re-sorts into registration order.
+    int x = p->t_x0, xc = p->cin0;
+    std::vector<int> hid, hidc;
+    for (int lv = 0; lv < p->nlev; ++lv) {
+        const int co = p->dims[lv + 1];
+        char nm[64];
+        snprintf(nm, sizeof nm, "downs.%d.0", lv);
+        x = add_resnet(p, nm, x, xc, -1, 0, co, lv);
+        snprintf(nm, sizeof nm, "downs.%d.1", lv);
+        x = add_resnet(p, nm, x, co, -1, 0, co, lv);
+        snprintf(nm, sizeof nm, "downs.%d.2", lv);
+        x = add_attn(p, nm, x, co, lv);
+        hid.push_back(x);
+        hidc.push_back(co);
+        if (lv < p->nlev - 1) {
+            snprintf(nm, sizeof nm, "downs.%d.3", lv);
+            x = add_resample(p, nm, x, co, lv, true);
+        }
+        xc = co;
+    }
+    const int mid = p->dims[p->nlev], lmid = p->nlev - 1;
+    x = add_resnet(p, "mid_block1", x, mid, -1, 0, mid, lmid);
+    x = add_attn(p, "mid_attn", x, mid, lmid);
+    x = add_resnet(p, "mid_block2", x, mid, -1, 0, mid, lmid);
+    xc = mid;
+    for (int u = 0; u < p->nlev - 1; ++u) {
+        const int lv = p->nlev - 1 - u;          // level this stage runs at
+        const int ci = p->dims[lv];              // dim_in of the stage (output channels)
+        const int co = p->dims[lv + 1];          // dim_out (== current x channels == skip channels)
+        char nm[64];
+        const int skip = hid.back(); hid.pop_back();
+        const int skc = hidc.back(); hidc.pop_back();
+        (void)co;
+        snprintf(nm, sizeof nm, "ups.%d.0", u);
+        x = add_resnet(p, nm, x, xc, skip, skc, ci, lv);      // torch.cat((x, hiddens.pop()), 1)  :207
+        snprintf(nm, sizeof nm, "ups.%d.1", u);
+        x = add_resnet(p, nm, x, ci, -1, 0, ci, lv);
+        snprintf(nm, sizeof nm, "ups.%d.2", u);
+        x = add_attn(p, nm, x, ci, lv);
+        snprintf(nm, sizeof nm, "ups.%d.3", u);
+        x = add_resample(p, nm, x, ci, lv, false);
+        xc = ci;
+    }
+    int fsc, fsh, fraw;
+    add_block(p, "final_block.", "final_block", x, xc, -1, 0, dim, 0, PRO_MASK, -1, -1, 0, &fraw, &fsc, &fsh);
+    p->t_final_raw = fraw; p->t_final_sc = fsc; p->t_final_sh = fsh;
+    add_param(p, "final_conv.weight", {1, dim, 1, 1}, 0);
+    add_param(p, "final_conv.bias", {1}, 0);
+    p->fw_off = poff(p, "final_conv.weight");
+    p->fb_off = poff(p, "final_conv.bias");
+
+    TimeMlpDesc &tm = p->tmlp;
+    tm.temb_off = tm.n ? tm.off[tm.n - 1] + tm.cout[tm.n - 1] : 0;
+    tm.tb_stride = tm.temb_off + dim;
+    if (tm.n > 32) { delete p; return fail(GTTS_E_CONFIG, "too many ResnetBlocks"); }
+    for (const Op &o : p->ops)
+        if (o.kind == OP_CONV && o.c1 > 0 && (o.c0 % 8) != 0) { delete p; return fail(GTTS_E_CONFIG, "concat split must be a multiple of 8 channels"); }
+    compute_liveness(p);
+    *out = p;
+    return GTTS_OK;
+}
+
+extern "C" void gtts_plan_destroy(gtts_plan *plan) { delete plan; }
+
+// registration order: spk_mlp, mlp, downs, ups, mid_block1, mid_attn, mid_block2, final_block, final_conv
+static int reg_rank(const std::string &n) {
+    if (n.rfind("spk_mlp", 0) == 0) return 0;
+    if (n.rfind("mlp.", 0) == 0) return 1;
+    if (n.rfind("downs", 0) == 0) return 2;
+    if (n.rfind("ups", 0) == 0) return 3;
+    if (n.rfind("mid_block1", 0) == 0) return 4;
+    if (n.rfind("mid_attn", 0) == 0) return 5;
+    if (n.rfind("mid_block2", 0) == 0) return 6;
+    if (n.rfind("final_block", 0) == 0) return 7;
+    return 8;
+}
+static std::vector<int> reg_order(const gtts_plan *p) {
+    std::vector<int> idx(p->params.size());
+    for (size_t i = 0; i < idx.size(); ++i) idx[i] = (int)i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return reg_rank(p->params[a].name) < reg_rank(p->params[b].name); });
+    return idx;
+}
+
+extern "C" int gtts_plan_num_params(const gtts_plan *plan) { return plan ? (int)plan->params.size() : 0; }
+
+extern "C" int gtts_plan_param_info(const gtts_plan *plan, int i, const char **name, int *rank, int dims[4]) {
+    if (!plan) return fail(GTTS_E_NULL, "null plan");
+    if (i < 0 || i >= (int)plan->params.size()) return fail(GTTS_E_SHAPE, "parameter index %d out of range", i);
+    const ParamDesc &d = plan->params[reg_order(plan)[i]];
+    if (name) *name = d.name.c_str();
+    if (rank) *rank = d.rank;
+    if (dims) for (int k = 0; k < 4; ++k) dims[k] = d.dims[k];
+    return GTTS_OK;
+}
+
+extern "C" size_t gtts_packed_weight_bytes(const gtts_plan *plan) { return plan ? plan->blob_bytes : 0; }
+
+extern "C" int gtts_pack_weights(const gtts_plan *plan, const void *const *param_ptrs, int n_params, const float *freq,
+                                 void *packed, gtts_stream_t stream) {
+    if (!plan || !param_ptrs || !packed || !freq) return fail(GTTS_E_NULL, "gtts_pack_weights: null argument");
+    if (n_params != (int)plan->params.size()) return fail(GTTS_E_PARAMS, "expected %d parameters, got %d", (int)plan->params.size(), n_params);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char *blob = (unsigned char *)packed;
+    HIPCHK(hipMemsetAsync(blob, 0, plan->blob_bytes, st));
+    HIPCHK(launch_copy_f32(freq, (float *)(blob + plan->freq_off), plan->cfg.dim / 2, st));
+    std::vector<int> order = reg_order(plan);
+    for (int i = 0; i < n_params; ++i) {
+        const ParamDesc &d = plan->params[order[i]];
+        const float *src = (const float *)param_ptrs[i];
+        if (!src) return fail(GTTS_E_NULL, "parameter %s is null", d.name.c_str());
+        size_t n = 1;
+        for (int k = 0; k < d.rank; ++k) n *= (size_t)d.dims[k];
+        switch (d.pack) {
+            case 0: HIPCHK(launch_copy_f32(src, (float *)(blob + d.off), n, st)); break;
+            case 1: HIPCHK(launch_pack_conv(CONV_C3, src, blob + d.off, d.cin, d.cout, st)); break;
+            case 2: HIPCHK(launch_pack_conv(CONV_DN, src, blob + d.off, d.cin, d.cout, st)); break;
+            case 3: HIPCHK(launch_pack_conv(CONV_UP, src, blob + d.off, d.cin, d.cout, st)); break;
+            case 4: HIPCHK(launch_pack_conv(CONV_P1, src, blob + d.off, d.cin, d.cout, st)); break;
+            case 5:
+                HIPCHK(launch_pack_attn_kv(src, blob + d.off, d.cin, st));
+                HIPCHK(launch_copy_f32(src, (float *)(blob + d.off2), (size_t)128 * d.cin, st));   // q rows 0..127
+                break;
+        }
+    }
+    return GTTS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ workspace
+static size_t tensor_bytes(const gtts_plan *p, const Tensor &t, int B, int T, int rows) {
+    const int F = p->cfg.n_feats;
+    const size_t H = (size_t)F >> t.lvl, W = (size_t)T >> t.lvl;
+    switch (t.kind) {
+        case TK_ACT: return (size_t)B * t.C * H * W * 4;
+        case TK_PERB: return (size_t)B * t.C * 4;
+        case TK_PART: return (size_t)B * conv_nparts(t.mode, t.cout, (int)H, (int)W) * t.C * 2 * 4;
+        case TK_APART: return (size_t)B * 4 * attn_geom((int)(H * W)).nrec * ATTN_REC * 4;
+        case TK_BYTES_PERB: return (size_t)B * t.bytes;
+        case TK_ROWS: return ((size_t)rows * p->tmlp.tb_stride + 4096) * 4;   // + the sampler's step times
+    }
+    return 0;
+}
+
+// (B,T) -> offsets.  keep_intermediates: every tensor gets its own slot; otherwise first-fit reuse by liveness.
+static void layout_workspace(gtts_plan *p, int B, int T, int rows) {
+    if (p->cache_B == B && p->cache_T == T * 4096 + rows) return;
+    const int n = (int)p->tensors.size();
+    p->offsets.assign(n, 0);
+    std::vector<size_t> sz(n);
+    for (int i = 0; i < n; ++i) sz[i] = align_up(tensor_bytes(p, p->tensors[i], B, T, rows), 256);
+    size_t top = 0;
+    if (p->cfg.keep_intermediates) {
+        for (int i = 0; i < n; ++i) { p->offsets[i] = top; top += sz[i]; }
+    } else {
+        struct Blk { size_t off, size; int last; };
+        std::vector<Blk> live;
+        std::vector<int> order(n);
+        for (int i = 0; i < n; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return p->tensors[a].first < p->tensors[b].first; });
+        for (int id : order) {
+            const Tensor &t = p->tensors[id];
+            if (t.last < 0) continue;     // never used
+            // drop blocks whose tensor died before this one is first written
+            live.erase(std::remove_if(live.begin(), live.end(), [&](const Blk &b) { return b.last < t.first; }), live.end());
+            std::sort(live.begin(), live.end(), [](const Blk &a, const Blk &b) { return a.off < b.off; });
+            size_t pos = 0;
+            for (const Blk &b : live) {
+                if (pos + sz[id] <= b.off) break;
+                pos = std::max(pos, b.off + b.size);
+            }
+            p->offsets[id] = pos;
+            live.push_back({pos, sz[id], t.last});
+            top = std::max(top, pos + sz[id]);
+        }
+    }
+    p->ws_bytes = top;
+    p->cache_B = B;
+    p->cache_T = T * 4096 + rows;
+}
+
+static int check_shape(const gtts_plan *p, int B, int T) {
+    if (!p) return fail(GTTS_E_NULL, "null plan");
+    if (B <= 0 || T <= 0) return fail(GTTS_E_SHAPE, "B and T must be positive (B=%d, T=%d)", B, T);
+    if (T % 4 != 0) return fail(GTTS_E_SHAPE, "T must be a multiple of 4 (fix_len_compatibility), got %d", T);
+    return GTTS_OK;
+}
+
+extern "C" size_t gtts_workspace_bytes(const gtts_plan *plan, int B, int T) {
+    if (check_shape(plan, B, T) != GTTS_OK) return 0;
+    gtts_plan *p = const_cast<gtts_plan *>(plan);
+    // sized for the sampler's worst case: one tb row per step is tiny, allow up to 4096 rows
+    layout_workspace(p, B, T, std::max(B, 4096));
+    return p->ws_bytes;
+}
+
+extern "C" int gtts_plan_num_tensors(const gtts_plan *plan) { return plan ? (int)plan->tensors.size() : 0; }
+
+extern "C" int gtts_plan_tensor_info(const gtts_plan *plan, int i, int B, int T, const char **name, size_t *offset,
+                                     int dims[4]) {
+    if (check_shape(plan, B, T) != GTTS_OK) return GTTS_E_SHAPE;
+    if (i < 0 || i >= (int)plan->tensors.size()) return fail(GTTS_E_SHAPE, "tensor index out of range");
+    gtts_plan *p = const_cast<gtts_plan *>(plan);
+    layout_workspace(p, B, T, std::max(B, 4096));
+    const Tensor &t = p->tensors[i];
+    if (name) *name = t.name.c_str();
+    if (offset) *offset = p->offsets[i];
+    if (dims) {
+        dims[0] = B; dims[1] = t.C; dims[2] = p->cfg.n_feats >> t.lvl; dims[3] = T >> t.lvl;
+        if (t.kind != TK_ACT) { dims[2] = 1; dims[3] = 1; }
+        if (t.kind == TK_ROWS) { dims[0] = B; dims[1] = p->tmlp.tb_stride; }   // first B rows (estimator call)
+    }
+    return GTTS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ execution
+struct RunCtx {
+    const gtts_plan *p;
+    const unsigned char *blob;
+    unsigned char *ws;
+    const float *mask;
+    int B, T;
+    const float *tb_row;   // tb rows of this call
+    int tb_bstride;        // floats between samples' rows (0: one row shared by the batch)
+    hipStream_t st;
+};
+
+static inline float *tptr(const RunCtx &c, int id) { return id < 0 ? nullptr : (float *)(c.ws + c.p->offsets[id]); }
+
+static int run_ops(const RunCtx &c) {
+    const gtts_plan *p = c.p;
+    const int F = p->cfg.n_feats, nsplit = p->cfg.precision == GTTS_PREC_BF16 ? 1 : 2;
+    for (const Op &o : p->ops) {
+        switch (o.kind) {
+            case OP_CONV: {
+                ConvArgs a;
+                memset(&a, 0, sizeof(a));
+                a.src0 = tptr(c, o.src0);
+                a.src1 = o.src1 >= 0 ? tptr(c, o.src1) : a.src0;
+                a.c0 = o.c0; a.c1 = o.c1; a.cin = o.c0 + o.c1; a.nchunk = (a.cin + 15) / 16;
+                a.B = c.B;
+                a.Hin = F >> o.lvl_in; a.Win = c.T >> o.lvl_in;
+                a.Hout = F >> o.lvl_out; a.Wout = c.T >> o.lvl_out;
+                a.mask = c.mask; a.T = c.T; a.lvl_in = o.lvl_in; a.lvl_out = o.lvl_out;
+                a.pro = o.pro;
+                a.sc = tptr(c, o.sc); a.sh = tptr(c, o.sh);
+                a.tb = c.tb_row + o.tb_off; a.tb_stride = c.tb_bstride;
+                if (o.w_t >= 0) {
+                    a.w = (const unsigned char *)tptr(c, o.w_t);
+                    a.w_bstride = p->tensors[o.w_t].bytes;
+                    a.bias = tptr(c, o.bias_t);
+                    a.bias_bstride = (size_t)o.cout;
+                } else {
+                    a.w = c.blob + o.w_off; a.w_bstride = 0;
+                    a.bias = (const float *)(c.blob + o.b_off); a.bias_bstride = 0;
+                }
+                a.cout = o.cout; a.epi = o.epi;
+                a.out = tptr(c, o.out);
+                a.partials = tptr(c, o.part);
+                a.nparts = conv_nparts(o.mode, o.cout, a.Hout, a.Wout);
+                a.groups = p->cfg.groups;
+                a.eh = tptr(c, o.eh); a.esc = tptr(c, o.esc); a.esh = tptr(c, o.esh); a.eres = tptr(c, o.eres);
+                a.nsplit = nsplit;
+                hipError_t e = launch_conv(o.mode, a, c.st);
+                if (e != hipSuccess) return fail(GTTS_E_HIP, "conv %s: %s", o.label.c_str(), hipGetErrorString(e));
+                break;
+            }
+            case OP_GNFIN: {
+                const int H = F >> o.lvl_in, W = c.T >> o.lvl_in;
+                const Tensor &pt = p->tensors[o.part];
+                hipError_t e = launch_gn_finalize(tptr(c, o.part), conv_nparts(pt.mode, pt.cout, H, W), p->cfg.groups, o.C,
+                                                  H * W, (const float *)(c.blob + o.gamma_off),
+                                                  (const float *)(c.blob + o.beta_off), tptr(c, o.sc), tptr(c, o.sh), c.B, c.st);
+                if (e != hipSuccess) return fail(GTTS_E_HIP, "gn_finalize %s: %s", o.label.c_str(), hipGetErrorString(e));
+                break;
+            }
+            case OP_TAILID: {
+                const int H = F >> o.lvl_in, W = c.T >> o.lvl_in;
+                hipError_t e = launch_tail_identity(tptr(c, o.eh), tptr(c, o.src0), tptr(c, o.esc), tptr(c, o.esh), c.mask,
+                                                    tptr(c, o.out), c.B, o.C, H, W, c.T, o.lvl_in, c.st);
+                if (e != hipSuccess) return fail(GTTS_E_HIP, "tail %s: %s", o.label.c_str(), hipGetErrorString(e));
+                break;
+            }
+            case OP_ACTX: {
+                const int HW = (F >> o.lvl_in) * (c.T >> o.lvl_in);
+                hipError_t e = launch_attn_ctx(tptr(c, o.src0), c.blob + o.wkv_off, tptr(c, o.apart), c.B, o.C, HW, nsplit, c.st);
+                if (e != hipSuccess) return fail(GTTS_E_HIP, "attn_ctx %s: %s", o.label.c_str(), hipGetErrorString(e));
+                break;
+            }
+            case OP_AMERGE: {
+                const int HW = (F >> o.lvl_in) * (c.T >> o.lvl_in);
+                hipError_t e = launch_attn_merge(tptr(c, o.apart), tptr(c, o.ctxn), c.B, attn_geom(HW).nrec, c.st);
+                if (e != hipSuccess) return fail(GTTS_E_HIP, "attn_merge %s: %s", o.label.c_str(), hipGetErrorString(e));
+                break;
+            }
+            case OP_AFOLD: {
+                hipError_t e = launch_attn_fold(tptr(c, o.ctxn), (const float *)(c.blob + o.wq_off),
+                                                (const float *)(c.blob + o.wout_off), (const float *)(c.blob + o.bout_off),
+                                                (const float *)(c.blob + o.g_off), (unsigned char *)tptr(c, o.w_t),
+                                                p->tensors[o.w_t].bytes, tptr(c, o.bias_t), c.B, o.C, c.st);
+                if (e != hipSuccess) return fail(GTTS_E_HIP, "attn_fold %s: %s", o.label.c_str(), hipGetErrorString(e));
+                break;
+            }
+        }
+    }
+    return GTTS_OK;
+}
+
+// t == nullptr: device computes t_i = float(1 - (i + 0.5)/n) per row (the sampler's schedule, diffusion.py:259)
+__global__ void sampler_times_kernel(float *t, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) t[i] = (float)(1.0 - ((double)i + 0.5) * (1.0 / (double)n));
+}
+
+static int prepare(gtts_plan *p, int B, int T, int rows, size_t workspace_bytes) {
+    layout_workspace(p, B, T, std::max(B, 4096));
+    (void)rows;
+    if (workspace_bytes < p->ws_bytes) return fail(GTTS_E_WORKSPACE, "workspace too small: need %zu bytes, got %zu", p->ws_bytes, workspace_bytes);
+    return GTTS_OK;
+}
+
+extern "C" int gtts_estimator_forward(const gtts_plan *plan, const void *packed, const float *x, const float *mask,
+                                      const float *mu, const float *t, const float *spk, float *out, void *workspace,
+                                      size_t workspace_bytes, int B, int T, gtts_stream_t stream) {
+    int rc = check_shape(plan, B, T);
+    if (rc) return rc;
+    if (!packed || !x || !mask || !mu || !t || !out || !workspace) return fail(GTTS_E_NULL, "gtts_estimator_forward: null argument");
+    gtts_plan *p = const_cast<gtts_plan *>(plan);
+    const bool multi = p->cfg.n_spks > 1;
+    if (multi && !spk) return fail(GTTS_E_NULL, "multi-speaker plan needs spk");
+    rc = prepare(p, B, T, B, workspace_bytes);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned char *blob = (const unsigned char *)packed;
+    RunCtx c{p, blob, (unsigned char *)workspace, mask, B, T, nullptr, 0, st};
+    const int F = p->cfg.n_feats;
+    float *s = nullptr;
+    if (multi) {
+        s = tptr(c, p->t_s);
+        HIPCHK(launch_spk_mlp(spk, (const float *)(blob + p->spk_w0), (const float *)(blob + p->spk_b0),
+                              (const float *)(blob + p->spk_w2), (const float *)(blob + p->spk_b2), s, B, p->cfg.spk_emb_dim, F, st));
+    }
+    float *tb = tptr(c, p->t_tb);
+    HIPCHK(launch_time_mlp(t, (const float *)(blob + p->freq_off), p->cfg.pe_scale, blob, p->tmlp, tb, B, st));
+    c.tb_row = tb;
+    c.tb_bstride = p->tmlp.tb_stride;
+    HIPCHK(launch_prep_input(mu, x, s, tptr(c, p->t_x0), B, F, T, p->cin0, st));
+    rc = run_ops(c);
+    if (rc) return rc;
+    HIPCHK(launch_final_euler(tptr(c, p->t_final_raw), tptr(c, p->t_final_sc), tptr(c, p->t_final_sh),
+                              (const float *)(blob + p->fw_off), (const float *)(blob + p->fb_off), mask, B, p->cfg.dim, F, T,
+                              out, nullptr, nullptr, nullptr, 0.f, 0.f, st));
+    return GTTS_OK;
+}
+
+extern "C" int gtts_euler_step(float *xt, const float *mu, const float *est, const float *mask, const float *noise,
+                               float beta_t, float h, int B, int F, int T, gtts_stream_t stream) {
+    if (!xt || !mu || !est || !mask) return fail(GTTS_E_NULL, "gtts_euler_step: null argument");
+    if (B <= 0 || F <= 0 || T <= 0) return fail(GTTS_E_SHAPE, "gtts_euler_step: bad shape");
+    HIPCHK(launch_euler_step(xt, mu, est, mask, noise, beta_t, h, B, F, T, (hipStream_t)stream));
+    return GTTS_OK;
+}
+
+extern "C" int gtts_reverse_diffusion(const gtts_plan *plan, const void *packed, const float *z, const float *mask,
+                                      const float *mu, const float *spk, const float *noise, float *out, void *workspace,
+                                      size_t workspace_bytes, int B, int T, int n_timesteps, gtts_stream_t stream) {
+    int rc = check_shape(plan, B, T);
+    if (rc) return rc;
+    if (!packed || !z || !mask || !mu || !out || !workspace) return fail(GTTS_E_NULL, "gtts_reverse_diffusion: null argument");
+    if (n_timesteps <= 0 || n_timesteps > 4096) return fail(GTTS_E_SHAPE, "n_timesteps must be in [1, 4096], got %d", n_timesteps);
+    gtts_plan *p = const_cast<gtts_plan *>(plan);
+    const bool multi = p->cfg.n_spks > 1;
+    if (multi && !spk) return fail(GTTS_E_NULL, "multi-speaker plan needs spk");
+    rc = prepare(p, B, T, n_timesteps, workspace_bytes);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned char *blob = (const unsigned char *)packed;
+    RunCtx c{p, blob, (unsigned char *)workspace, mask, B, T, nullptr, 0, st};
+    const int F = p->cfg.n_feats, N = n_timesteps;
+    float *s = nullptr;
+    if (multi) {
+        s = tptr(c, p->t_s);
+        HIPCHK(launch_spk_mlp(spk, (const float *)(blob + p->spk_w0), (const float *)(blob + p->spk_b0),
+                              (const float *)(blob + p->spk_w2), (const float *)(blob + p->spk_b2), s, B, p->cfg.spk_emb_dim, F, st));
+    }
+    // time embeddings of all N steps in one launch: t is batch-uniform inside the sampler (diffusion.py:259).
+    // The step times live in the 4096 floats behind the tb rows.
+    float *tb = tptr(c, p->t_tb);
+    float *tvals = tb + (size_t)std::max(B, 4096) * p->tmlp.tb_stride;
+    hipLaunchKernelGGL(sampler_times_kernel, dim3((N + 255) / 256), dim3(256), 0, st, tvals, N);
+    HIPCHK(hipGetLastError());
+    HIPCHK(launch_time_mlp(tvals, (const float *)(blob + p->freq_off), p->cfg.pe_scale, blob, p->tmlp, tb, N, st));
+    HIPCHK(launch_mul_mask(z, mask, out, B, F, T, st));           // xt = z * mask        (diffusion.py:257)
+    const double hd = 1.0 / (double)N;
+    const float h = (float)hd;
+    const float bmin = p->cfg.beta_min, bdiff = (float)((double)p->cfg.beta_max - (double)p->cfg.beta_min);
+    for (int i = 0; i < N; ++i) {
+        const float t = (float)(1.0 - ((double)i + 0.5) * hd);
+        const float beta = bmin + bdiff * t;                      // get_noise, fp32 like the reference tensor math
+        c.tb_row = tb + (size_t)i * p->tmlp.tb_stride;
+        c.tb_bstride = 0;
+        HIPCHK(launch_prep_input(mu, out, s, tptr(c, p->t_x0), B, F, T, p->cin0, st));
+        rc = run_ops(c);
+        if (rc) return rc;
+        const float *nz = noise ? noise + (size_t)i * B * F * T : nullptr;
+        HIPCHK(launch_final_euler(tptr(c, p->t_final_raw), tptr(c, p->t_final_sc), tptr(c, p->t_final_sh),
+                                  (const float *)(blob + p->fw_off), (const float *)(blob + p->fb_off), mask, B, p->cfg.dim, F, T,
+                                  nullptr, out, mu, nz, beta, h, st));
+    }
+    return GTTS_OK;
+}
+
+extern "C" size_t gtts_mas_scratch_bytes(int b, int tx, int ty) {
+    if (b <= 0 || tx <= 0 || ty <= 0) return 0;
+    return (size_t)b * tx * ty;
+}
+
+extern "C" int gtts_mas_maximum_path(const float *value, const float *mask, const int *t_x, const int *t_y, int *path,
+                                     void *scratch, int b, int tx, int ty, gtts_stream_t stream) {
+    if (!value || !t_x || !t_y || !path || !scratch) return fail(GTTS_E_NULL, "gtts_mas_maximum_path: null argument");
+    if (b <= 0 || tx <= 0 || ty <= 0) return fail(GTTS_E_SHAPE, "gtts_mas_maximum_path: bad shape b=%d tx=%d ty=%d", b, tx, ty);
+    if ((size_t)2 * tx * 4 > 160 * 1024) return fail(GTTS_E_SHAPE, "t_x too large for the LDS column buffer (%d)", tx);
+    HIPCHK(launch_mas(value, mask, t_x, t_y, path, (unsigned char *)scratch, b, tx, ty, (hipStream_t)stream));
+    return GTTS_OK;
+}
