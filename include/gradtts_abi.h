@@ -116,6 +116,19 @@ int gtts_plan_num_tensors(const gtts_plan *plan);
 int gtts_plan_tensor_info(const gtts_plan *plan, int i, int B, int T, const char **name, size_t *offset,
                           int dims[4]);
 
+/* ---- measurement: per-op HIP-event timing of the op program (bench.py roofline) ------------------------- */
+/* Ops are the kernel launches of one estimator call, in launch order; label = layer name, kernel = the HIP kernel
+ * (template instance) it launches, flops / bytes = ALGORITHMIC work of that launch for the given (B,T)
+ * (SURVEY.md section 8d model: each tensor read once, written once). */
+int gtts_plan_num_ops(const gtts_plan *plan);
+int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, const char **label, const char **kernel,
+                      double *flops, double *bytes);
+/* on != 0: every later estimator / sampler call brackets each op launch with hipEventRecord on the call's stream. */
+int gtts_profile_enable(gtts_plan *plan, int on);
+/* Synchronises the recorded events, adds elapsed milliseconds and launch counts per op into the two arrays
+ * (length gtts_plan_num_ops) and clears the record. */
+int gtts_profile_collect(gtts_plan *plan, double *ms_per_op, long long *launches_per_op);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,11 @@ def lib():
         L.gtts_plan_num_tensors.argtypes = [vp]
         L.gtts_plan_tensor_info.argtypes = [vp, i, i, i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz),
                                             ctypes.POINTER(i * 4)]
+        L.gtts_plan_num_ops.argtypes = [vp]
+        L.gtts_plan_op_info.argtypes = [vp, i, i, i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p),
+                                        ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        L.gtts_profile_enable.argtypes = [vp, i]
+        L.gtts_profile_collect.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]
         if L.gtts_abi_version() != 1:
             raise RuntimeError("libgradtts_gfx950.so ABI version mismatch")
         _lib = L
@@ -199,6 +204,29 @@ class Plan:
                                                 _ptr(noise), _ptr(out), _ptr(ws), ws.numel(), B, T, int(n_timesteps),
                                                 _stream()), "gtts_reverse_diffusion")
         return out
+
+    # ---- measurement (bench.py): per-op HIP-event timing
+    def ops(self, B, T):
+        """[(label, kernel, algorithmic flops, algorithmic bytes)] of the launches of one estimator call."""
+        L = lib()
+        out = []
+        for k in range(L.gtts_plan_num_ops(self._h)):
+            label, kern, fl, by = ctypes.c_char_p(), ctypes.c_char_p(), ctypes.c_double(), ctypes.c_double()
+            _check(L.gtts_plan_op_info(self._h, k, int(B), int(T), ctypes.byref(label), ctypes.byref(kern),
+                                       ctypes.byref(fl), ctypes.byref(by)), "gtts_plan_op_info")
+            out.append((label.value.decode(), kern.value.decode(), fl.value, by.value))
+        return out
+
+    def profile(self, on):
+        _check(lib().gtts_profile_enable(self._h, 1 if on else 0), "gtts_profile_enable")
+
+    def profile_collect(self):
+        """(ms per op, launches per op) accumulated since profiling was enabled; clears the record."""
+        n = lib().gtts_plan_num_ops(self._h)
+        ms = (ctypes.c_double * n)()
+        cnt = (ctypes.c_longlong * n)()
+        _check(lib().gtts_profile_collect(self._h, ms, cnt), "gtts_profile_collect")
+        return list(ms), list(cnt)
 
     # ---- debugging: named intermediates (keep_intermediates plans)
     def tensors(self, B, T, device):

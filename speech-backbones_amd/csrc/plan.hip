@@ -97,6 +97,12 @@ struct gtts_plan {
     std::vector<Op> ops;
     int t_x0, t_s, t_tb, t_final_raw, t_final_sc, t_final_sh;
     size_t fw_off, fb_off;     // final_conv weight / bias (fp32)
+    // extra (non-program) launches, profiled as ops n_ops .. n_ops+3: prep_input, time_mlp, final_euler, mul_mask
+    // profiling
+    bool prof_on = false;
+    struct ProfRec { int op; hipEvent_t a, b; };
+    std::vector<ProfRec> prof;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
     // workspace layout cache
     int cache_B = -1, cache_T = -1;
     std::vector<size_t> offsets;
@@ -562,12 +568,32 @@ struct RunCtx {
     hipStream_t st;
 };
 
+enum { XOP_PREP = 0, XOP_TIME = 1, XOP_FINAL = 2, XOP_MULMASK = 3, XOP_SPK = 4, XOP_COUNT = 5 };
+
+struct ProfScope {
+    gtts_plan *p;
+    hipStream_t st;
+    int idx;
+    ProfScope(const gtts_plan *plan, hipStream_t s, int op) : p(const_cast<gtts_plan *>(plan)), st(s), idx(-1) {
+        if (!p->prof_on) return;
+        std::pair<hipEvent_t, hipEvent_t> ev;
+        if (!p->prof_pool.empty()) { ev = p->prof_pool.back(); p->prof_pool.pop_back(); }
+        else { if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) return; }
+        p->prof.push_back({op, ev.first, ev.second});
+        idx = (int)p->prof.size() - 1;
+        (void)hipEventRecord(ev.first, st);
+    }
+    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(p->prof[idx].b, st); }
+};
+
 static inline float *tptr(const RunCtx &c, int id) { return id < 0 ? nullptr : (float *)(c.ws + c.p->offsets[id]); }
 
 static int run_ops(const RunCtx &c) {
     const gtts_plan *p = c.p;
     const int F = p->cfg.n_feats, nsplit = p->cfg.precision == GTTS_PREC_BF16 ? 1 : 2;
-    for (const Op &o : p->ops) {
+    for (size_t oi = 0; oi < p->ops.size(); ++oi) {
+        const Op &o = p->ops[oi];
+        ProfScope prof_scope(p, c.st, (int)oi);
         switch (o.kind) {
             case OP_CONV: {
                 ConvArgs a;
@@ -674,19 +700,19 @@ extern "C" int gtts_estimator_forward(const gtts_plan *plan, const void *packed,
     float *s = nullptr;
     if (multi) {
         s = tptr(c, p->t_s);
-        HIPCHK(launch_spk_mlp(spk, (const float *)(blob + p->spk_w0), (const float *)(blob + p->spk_b0),
-                              (const float *)(blob + p->spk_w2), (const float *)(blob + p->spk_b2), s, B, p->cfg.spk_emb_dim, F, st));
+        { ProfScope ps_(p, st, (int)p->ops.size() + XOP_SPK); HIPCHK(launch_spk_mlp(spk, (const float *)(blob + p->spk_w0), (const float *)(blob + p->spk_b0),
+                              (const float *)(blob + p->spk_w2), (const float *)(blob + p->spk_b2), s, B, p->cfg.spk_emb_dim, F, st)); }
     }
     float *tb = tptr(c, p->t_tb);
-    HIPCHK(launch_time_mlp(t, (const float *)(blob + p->freq_off), p->cfg.pe_scale, blob, p->tmlp, tb, B, st));
+    { ProfScope ps_(p, st, (int)p->ops.size() + XOP_TIME); HIPCHK(launch_time_mlp(t, (const float *)(blob + p->freq_off), p->cfg.pe_scale, blob, p->tmlp, tb, B, st)); }
     c.tb_row = tb;
     c.tb_bstride = p->tmlp.tb_stride;
-    HIPCHK(launch_prep_input(mu, x, s, tptr(c, p->t_x0), B, F, T, p->cin0, st));
+    { ProfScope ps_(p, st, (int)p->ops.size() + XOP_PREP); HIPCHK(launch_prep_input(mu, x, s, tptr(c, p->t_x0), B, F, T, p->cin0, st)); }
     rc = run_ops(c);
     if (rc) return rc;
-    HIPCHK(launch_final_euler(tptr(c, p->t_final_raw), tptr(c, p->t_final_sc), tptr(c, p->t_final_sh),
+    { ProfScope ps_(p, st, (int)p->ops.size() + XOP_FINAL); HIPCHK(launch_final_euler(tptr(c, p->t_final_raw), tptr(c, p->t_final_sc), tptr(c, p->t_final_sh),
                               (const float *)(blob + p->fw_off), (const float *)(blob + p->fb_off), mask, B, p->cfg.dim, F, T,
-                              out, nullptr, nullptr, nullptr, 0.f, 0.f, st));
+                              out, nullptr, nullptr, nullptr, 0.f, 0.f, st)); }
     return GTTS_OK;
 }
 
@@ -717,8 +743,8 @@ extern "C" int gtts_reverse_diffusion(const gtts_plan *plan, const void *packed,
     float *s = nullptr;
     if (multi) {
         s = tptr(c, p->t_s);
-        HIPCHK(launch_spk_mlp(spk, (const float *)(blob + p->spk_w0), (const float *)(blob + p->spk_b0),
-                              (const float *)(blob + p->spk_w2), (const float *)(blob + p->spk_b2), s, B, p->cfg.spk_emb_dim, F, st));
+        { ProfScope ps_(p, st, (int)p->ops.size() + XOP_SPK); HIPCHK(launch_spk_mlp(spk, (const float *)(blob + p->spk_w0), (const float *)(blob + p->spk_b0),
+                              (const float *)(blob + p->spk_w2), (const float *)(blob + p->spk_b2), s, B, p->cfg.spk_emb_dim, F, st)); }
     }
     // time embeddings of all N steps in one launch: t is batch-uniform inside the sampler (diffusion.py:259).
     // The step times live in the 4096 floats behind the tb rows.
@@ -726,8 +752,8 @@ extern "C" int gtts_reverse_diffusion(const gtts_plan *plan, const void *packed,
     float *tvals = tb + (size_t)std::max(B, 4096) * p->tmlp.tb_stride;
     hipLaunchKernelGGL(sampler_times_kernel, dim3((N + 255) / 256), dim3(256), 0, st, tvals, N);
     HIPCHK(hipGetLastError());
-    HIPCHK(launch_time_mlp(tvals, (const float *)(blob + p->freq_off), p->cfg.pe_scale, blob, p->tmlp, tb, N, st));
-    HIPCHK(launch_mul_mask(z, mask, out, B, F, T, st));           // xt = z * mask        (diffusion.py:257)
+    { ProfScope ps_(p, st, (int)p->ops.size() + XOP_TIME); HIPCHK(launch_time_mlp(tvals, (const float *)(blob + p->freq_off), p->cfg.pe_scale, blob, p->tmlp, tb, N, st)); }
+    { ProfScope ps_(p, st, (int)p->ops.size() + XOP_MULMASK); HIPCHK(launch_mul_mask(z, mask, out, B, F, T, st)); }           // xt = z * mask        (diffusion.py:257)
     const double hd = 1.0 / (double)N;
     const float h = (float)hd;
     const float bmin = p->cfg.beta_min, bdiff = (float)((double)p->cfg.beta_max - (double)p->cfg.beta_min);
@@ -736,13 +762,13 @@ extern "C" int gtts_reverse_diffusion(const gtts_plan *plan, const void *packed,
         const float beta = bmin + bdiff * t;                      // get_noise, fp32 like the reference tensor math
         c.tb_row = tb + (size_t)i * p->tmlp.tb_stride;
         c.tb_bstride = 0;
-        HIPCHK(launch_prep_input(mu, out, s, tptr(c, p->t_x0), B, F, T, p->cin0, st));
+        { ProfScope ps_(p, st, (int)p->ops.size() + XOP_PREP); HIPCHK(launch_prep_input(mu, out, s, tptr(c, p->t_x0), B, F, T, p->cin0, st)); }
         rc = run_ops(c);
         if (rc) return rc;
         const float *nz = noise ? noise + (size_t)i * B * F * T : nullptr;
-        HIPCHK(launch_final_euler(tptr(c, p->t_final_raw), tptr(c, p->t_final_sc), tptr(c, p->t_final_sh),
+        { ProfScope ps_(p, st, (int)p->ops.size() + XOP_FINAL); HIPCHK(launch_final_euler(tptr(c, p->t_final_raw), tptr(c, p->t_final_sc), tptr(c, p->t_final_sh),
                                   (const float *)(blob + p->fw_off), (const float *)(blob + p->fb_off), mask, B, p->cfg.dim, F, T,
-                                  nullptr, out, mu, nz, beta, h, st));
+                                  nullptr, out, mu, nz, beta, h, st)); }
     }
     return GTTS_OK;
 }
@@ -758,5 +784,88 @@ extern "C" int gtts_mas_maximum_path(const float *value, const float *mask, cons
     if (b <= 0 || tx <= 0 || ty <= 0) return fail(GTTS_E_SHAPE, "gtts_mas_maximum_path: bad shape b=%d tx=%d ty=%d", b, tx, ty);
     if ((size_t)2 * tx * 4 > 160 * 1024) return fail(GTTS_E_SHAPE, "t_x too large for the LDS column buffer (%d)", tx);
     HIPCHK(launch_mas(value, mask, t_x, t_y, path, (unsigned char *)scratch, b, tx, ty, (hipStream_t)stream));
+    return GTTS_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------ measurement
+static std::string conv_kernel_name(int mode, int cout) {
+    const bool wide = cout > 64;
+    int wm, wn, mf;
+    if (mode == CONV_DN) { wm = 2; wn = 2; mf = wide ? 2 : 1; }
+    else if (wide) { wm = 2; wn = 2; mf = 2; }
+    else { wm = 1; wn = 4; mf = 2; }
+    char buf[96];
+    snprintf(buf, sizeof buf, "gtts::conv_mfma_kernel<%d, %d, %d, %d>", mode, wm, wn, mf);
+    return buf;
+}
+
+extern "C" int gtts_plan_num_ops(const gtts_plan *plan) { return plan ? (int)plan->ops.size() + XOP_COUNT : 0; }
+
+extern "C" int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, const char **label, const char **kernel,
+                                 double *flops, double *bytes) {
+    int rc = check_shape(plan, B, T);
+    if (rc) return rc;
+    static thread_local std::string s_label, s_kernel;
+    const int n = (int)plan->ops.size();
+    if (i < 0 || i >= n + XOP_COUNT) return fail(GTTS_E_SHAPE, "op index out of range");
+    const double F = plan->cfg.n_feats;
+    double fl = 0, by = 0;
+    if (i >= n) {
+        const double FT = F * T * B;
+        switch (i - n) {
+            case XOP_PREP: s_label = "prep_input"; s_kernel = "gtts::prep_input_kernel"; by = 4.0 * FT * 2 * plan->cin0; break;
+            case XOP_TIME: s_label = "time_mlp"; s_kernel = "gtts::time_mlp_kernel"; break;
+            case XOP_FINAL: s_label = "final_conv+euler"; s_kernel = "gtts::final_euler_kernel";
+                fl = 2.0 * plan->cfg.dim * FT; by = 4.0 * FT * (plan->cfg.dim + 4); break;
+            case XOP_MULMASK: s_label = "xt=z*mask"; s_kernel = "gtts::mul_mask_kernel"; by = 8.0 * FT; break;
+            case XOP_SPK: s_label = "spk_mlp"; s_kernel = "gtts::spk_mlp_kernel"; break;
+        }
+    } else {
+        const Op &o = plan->ops[i];
+        s_label = o.label;
+        const double Hi = (int)F >> o.lvl_in, Wi = T >> o.lvl_in, Ho = (int)F >> o.lvl_out, Wo = T >> o.lvl_out;
+        switch (o.kind) {
+            case OP_CONV: {
+                const double cin = o.c0 + o.c1;
+                const double taps = o.mode == CONV_P1 ? 1 : (o.mode == CONV_UP ? 4 : 9);
+                fl = 2.0 * B * o.cout * cin * taps * Ho * Wo;
+                by = 4.0 * B * (cin * Hi * Wi + o.cout * Ho * Wo);
+                if (o.epi == EPI_TAIL || o.epi == EPI_ATTN) by += 4.0 * B * o.cout * Ho * Wo;
+                s_kernel = conv_kernel_name(o.mode, o.cout);
+                break;
+            }
+            case OP_GNFIN: s_kernel = "gtts::gn_finalize_kernel"; break;
+            case OP_TAILID: s_kernel = "gtts::tail_identity_kernel"; by = 4.0 * B * o.C * Hi * Wi * 3; break;
+            case OP_ACTX: s_kernel = "gtts::attn_ctx_kernel"; fl = 2.0 * B * Hi * Wi * (256.0 * o.C + 128.0 * 32);
+                by = 4.0 * B * o.C * Hi * Wi; break;
+            case OP_AMERGE: s_kernel = "gtts::attn_merge_kernel"; break;
+            case OP_AFOLD: s_kernel = "gtts::attn_fold_kernel"; fl = 2.0 * B * (o.C * 128.0 * 32 + (double)o.C * o.C * 128); break;
+        }
+    }
+    if (label) *label = s_label.c_str();
+    if (kernel) *kernel = s_kernel.c_str();
+    if (flops) *flops = fl;
+    if (bytes) *bytes = by;
+    return GTTS_OK;
+}
+
+extern "C" int gtts_profile_enable(gtts_plan *plan, int on) {
+    if (!plan) return fail(GTTS_E_NULL, "null plan");
+    plan->prof_on = on != 0;
+    return GTTS_OK;
+}
+
+extern "C" int gtts_profile_collect(gtts_plan *plan, double *ms_per_op, long long *launches_per_op) {
+    if (!plan || !ms_per_op || !launches_per_op) return fail(GTTS_E_NULL, "gtts_profile_collect: null argument");
+    const int n = (int)plan->ops.size() + XOP_COUNT;
+    for (auto &r : plan->prof) {
+        HIPCHK(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+        if (r.op >= 0 && r.op < n) { ms_per_op[r.op] += ms; launches_per_op[r.op] += 1; }
+        plan->prof_pool.push_back({r.a, r.b});
+    }
+    plan->prof.clear();
     return GTTS_OK;
 }

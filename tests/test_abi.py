@@ -1,0 +1,61 @@
+"""CPU: the C-ABI library loads and exports exactly the symbols include/gradtts_abi.h declares; host-only entry
+points (plan creation, layouts, argument validation) behave; no compute call is made (no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT, pkg
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "gradtts_abi.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gtts_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported():
+    S = pkg()
+    assert os.path.exists(S._lib.LIB_PATH), "run __graft_entry__.build() first"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", S._lib.LIB_PATH]).decode()
+    exported = set(re.findall(r"\bT (gtts_[a-z_0-9]+)", out))
+    declared = _declared()
+    assert len(declared) >= 15
+    assert set(declared) <= exported, sorted(set(declared) - exported)
+    lib = ctypes.CDLL(S._lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name)
+
+
+def test_plan_layout_and_validation():
+    S = pkg()
+    from oracle import gradtts_oracle as O
+    for n_spks, n in ((1, 172), (247, 176)):
+        p = S.Plan(n_spks=n_spks)
+        layout = p.param_layout()
+        sd = O.make_estimator_state(n_spks=n_spks)
+        assert [k for k, _ in layout] == list(sd.keys())            # reference registration order
+        assert all(tuple(sd[k].shape) == s for k, s in layout)
+        assert len(layout) == n
+        assert p.packed_bytes() > 30e6
+        assert p.workspace_bytes(16, 1024) > p.workspace_bytes(2, 64) > 0
+    p = S.Plan()
+    with pytest.raises(RuntimeError):
+        p.workspace_bytes(1, 30)          # T % 4 != 0
+    with pytest.raises(RuntimeError):
+        S.Plan(groups=4)
+    with pytest.raises(RuntimeError):
+        S.Plan(dim=48)
+    assert S.Plan(keep_intermediates=True).workspace_bytes(2, 64) > S.Plan().workspace_bytes(2, 64)
+
+
+def test_no_cpu_fallback():
+    import torch
+    S = pkg()
+    p = S.Plan()
+    with pytest.raises(RuntimeError, match="HIP device"):
+        p.estimator_forward(None, torch.zeros(1, 80, 32), torch.ones(1, 1, 32), torch.zeros(1, 80, 32), torch.ones(1))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        S.mas_maximum_path(torch.zeros(1, 3, 5), torch.ones(1, 3, 5))

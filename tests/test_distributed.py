@@ -1,0 +1,72 @@
+"""CPU, world_size 2 over gloo: the N>1 path of bench.py -- contiguous utterance shards, one weight-blob broadcast,
+no data-path collective, concatenated shard results == unsharded result."""
+import importlib
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    D = importlib.import_module("speech-backbones_amd.dist")
+    r, w, _ = D.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    # weight blob: rank 0 "packs", the others receive
+    blob = torch.arange(1000, dtype=torch.uint8) if rank == 0 else torch.zeros(1000, dtype=torch.uint8)
+    D.broadcast_packed(blob, src=0)
+    ok_blob = bool(torch.equal(blob, torch.arange(1000, dtype=torch.uint8)))
+    # shard a batch of 5 utterances; per-sample "work" stands in for the sampler (it never mixes batch entries)
+    g = torch.Generator().manual_seed(0)
+    batch = torch.randn(5, 80, 8, generator=g)
+    lo, hi = D.shard_bounds(5, world, rank)
+    local = batch[lo:hi] * 2.0 + 1.0
+    outs = D.gather_outputs(local, dst=0)
+    t = D.max_over_ranks(1.0 + rank, torch.device("cpu"))
+    D.barrier()
+    if rank == 0:
+        q.put((ok_blob, bool(torch.equal(torch.cat(outs, 0), batch * 2.0 + 1.0)), t, (lo, hi)))
+    else:
+        q.put((ok_blob, True, t, (lo, hi)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_and_broadcast():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[0] and r[1] for r in res)
+    assert all(abs(r[2] - 2.0) < 1e-9 for r in res)           # max over ranks
+    assert sorted(r[3] for r in res) == [(0, 3), (3, 5)]
+
+
+def test_shard_helpers():
+    D = importlib.import_module("speech-backbones_amd.dist")
+    for n, w in [(16, 8), (5, 2), (3, 4), (128, 8)]:
+        b = [D.shard_bounds(n, w, r) for r in range(w)]
+        assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+    fb = D.shard_by_frames([100, 10, 10, 10, 100, 10], 2)
+    assert fb[0][0] == 0 and fb[-1][1] == 6 and fb[0][1] == fb[1][0]

@@ -1,0 +1,317 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle / golden vectors.
+
+Tolerances (fp32 storage, bf16x3 contractions with fp32 accumulation):
+  * integer / index work (MAS paths, alignment) and the Euler update given identical inputs: bit-exact.
+  * score-network output and sampled mels: max-abs error <= REL * max|ref| with REL = 1e-4 (measured ~2e-5), and
+    on mel-scale fixtures (outputs O(1..10)) the north-star's absolute bound 1e-3 max-abs.
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import gradtts_oracle as O
+from oracle import mas as MAS
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def S():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return importlib.import_module("speech-backbones_amd")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def relerr(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+_plans = {}
+
+
+def plan_for(S, dev, seed, n_spks=1):
+    key = (seed, n_spks)
+    if key not in _plans:
+        sd = O.make_estimator_state(seed=seed, n_spks=n_spks)
+        p = S.Plan(n_spks=n_spks)
+        _plans[key] = (sd, p, p.pack(sd, dev))
+    return _plans[key]
+
+
+# ------------------------------------------------------------------------------------------------ library
+def test_native_library_is_loaded(S):
+    assert S._lib.lib().gtts_abi_version() == 1
+    import os
+    assert os.path.exists(S._lib.LIB_PATH)
+
+
+# ------------------------------------------------------------------------------------------------ Euler update
+@pytest.mark.parametrize("stoc", [False, True])
+def test_euler_step_bit_exact(S, dev, stoc):
+    g = torch.Generator().manual_seed(3)
+    B, Fm, T = 3, 80, 52
+    xt, mu, est = (torch.randn(B, Fm, T, generator=g) for _ in range(3))
+    noise = torch.randn(B, Fm, T, generator=g) if stoc else None
+    mask = O.sequence_mask(torch.tensor([52, 40, 7]), T).unsqueeze(1).float()
+    for beta_t, h in [(19.8005, 0.02), (0.2495, 0.1), (7.03125, 1.0 / 3)]:
+        beta32 = float(np.float32(beta_t))
+        ref = O.euler_step(xt, mu, est, mask, beta32, h, noise)
+        got = S.euler_step(xt.clone().to(dev), mu.to(dev), est.to(dev), mask.to(dev), beta32, h,
+                           noise.to(dev) if stoc else None).cpu()
+        assert torch.equal(got, ref)
+
+
+# ------------------------------------------------------------------------------------------------ MAS
+def test_mas_golden_bit_exact(S, dev):
+    g = golden("mas.npz")
+    path = S.mas_maximum_path(_t(g["value"]).to(dev), _t(g["mask"]).float().to(dev)).cpu()
+    assert torch.equal(path.to(torch.uint8), _t(g["path"]))
+
+
+@pytest.mark.parametrize("b,tx,ty", [(4, 31, 90), (3, 1, 7), (2, 50, 50), (6, 13, 200), (16, 200, 1024), (2, 300, 1000)])
+def test_mas_random_ragged_bit_exact(S, dev, b, tx, ty):
+    g = torch.Generator().manual_seed(b * 1000 + tx)
+    value = torch.randn(b, tx, ty, generator=g) * 4
+    xl = torch.randint(1, tx + 1, (b,), generator=g)
+    xl[0] = tx
+    yl = torch.maximum(torch.randint(1, ty + 1, (b,), generator=g), xl)
+    yl[0] = ty
+    mask = (O.sequence_mask(xl, tx).unsqueeze(-1) * O.sequence_mask(yl, ty).unsqueeze(1)).float()
+    got = S.mas_maximum_path(value.to(dev), mask.to(dev)).cpu()
+    want = MAS.maximum_path_port(value, mask)
+    assert torch.equal(got, want)
+    # structural properties of a monotonic alignment (size independent)
+    for i in range(b):
+        p = got[i, : xl[i], : yl[i]]
+        assert torch.all(p.sum(0) == 1)                       # every frame belongs to exactly one token
+        idx = p.argmax(0)
+        assert idx[0] == 0 and idx[-1] == xl[i] - 1 and torch.all((idx[1:] - idx[:-1]).clamp(0, 1) == idx[1:] - idx[:-1])
+    assert float(got.sum()) == float(yl.sum())
+
+
+def test_mas_matches_compiled_reference_when_available(S, dev):
+    if not MAS.ref_available():
+        pytest.skip("oracle/_ref not present")
+    g = torch.Generator().manual_seed(42)
+    value = torch.randn(8, 60, 333, generator=g) * 5
+    xl = torch.randint(1, 61, (8,), generator=g)
+    yl = torch.maximum(torch.randint(1, 334, (8,), generator=g), xl)
+    mask = (O.sequence_mask(xl, 60).unsqueeze(-1) * O.sequence_mask(yl, 333).unsqueeze(1)).float()
+    assert torch.equal(S.mas_maximum_path(value.to(dev), mask.to(dev)).cpu(), MAS.maximum_path_ref(value, mask))
+
+
+# ------------------------------------------------------------------------------------------------ estimator
+def test_estimator_matches_reference_golden_single_speaker(S, dev):
+    g = golden("est_1spk.npz")
+    sd, plan, blob = plan_for(S, dev, int(g["seed"]))
+    out = plan.estimator_forward(blob, _t(g["z"]).to(dev), _t(g["mask"]).to(dev), _t(g["mu"]).to(dev), _t(g["t"]).to(dev)).cpu()
+    ref = _t(g["est"])
+    assert relerr(out, ref) <= REL
+    assert float((out - ref).abs().max()) <= 1e-3            # O(1) output scale: the north-star bound applies
+    assert float((out * (1 - _t(g["mask"]))).abs().max()) == 0.0
+
+
+def test_estimator_matches_reference_golden_multi_speaker(S, dev):
+    g = golden("est_3ch.npz")
+    sd, plan, blob = plan_for(S, dev, int(g["seed"]), n_spks=4)
+    out = plan.estimator_forward(blob, _t(g["z"]).to(dev), _t(g["mask"]).to(dev), _t(g["mu"]).to(dev), _t(g["t"]).to(dev),
+                                 _t(g["spk"]).to(dev)).cpu()
+    ref = _t(g["est"])
+    assert relerr(out, ref) <= REL
+    assert float((out - ref).abs().max()) <= 1e-3
+
+
+@pytest.mark.parametrize("B,T", [(1, 4), (1, 36), (3, 100), (2, 128), (5, 260)])
+def test_estimator_matches_oracle_odd_shapes(S, dev, B, T):
+    sd, plan, blob = plan_for(S, dev, 0)
+    inp = O.make_inputs(B, T, seed=B * 100 + T)
+    t = torch.linspace(0.05, 0.95, B)
+    ref = O.estimator_forward(sd, inp["z"], inp["mask"], inp["mu"], t)
+    out = plan.estimator_forward(blob, inp["z"].to(dev), inp["mask"].to(dev), inp["mu"].to(dev), t.to(dev)).cpu()
+    assert relerr(out, ref) <= REL
+
+
+def test_estimator_empty_and_tiny_utterances(S, dev):
+    """Edge cases: an all-masked utterance and a 1-frame utterance inside a batch (outputs exactly 0 where masked)."""
+    sd, plan, blob = plan_for(S, dev, 0)
+    inp = O.make_inputs(3, 32, seed=9)
+    mask = O.sequence_mask(torch.tensor([32, 0, 1]), 32).unsqueeze(1).float()
+    t = torch.full((3,), 0.5)
+    ref = O.estimator_forward(sd, inp["z"], mask, inp["mu"], t)
+    out = plan.estimator_forward(blob, inp["z"].to(dev), mask.to(dev), inp["mu"].to(dev), t.to(dev)).cpu()
+    assert torch.isfinite(out).all()
+    assert float(out[1].abs().max()) == 0.0
+    assert relerr(out, ref) <= REL
+
+
+def test_bad_arguments_fail_loudly(S, dev):
+    sd, plan, blob = plan_for(S, dev, 0)
+    z = torch.zeros(1, 80, 30, device=dev)          # T not a multiple of 4
+    with pytest.raises(RuntimeError):
+        plan.estimator_forward(blob, z, torch.ones(1, 1, 30, device=dev), z, torch.ones(1, device=dev))
+    with pytest.raises(RuntimeError):               # CPU tensor: no fallback
+        plan.estimator_forward(blob, torch.zeros(1, 80, 32), torch.ones(1, 1, 32), torch.zeros(1, 80, 32), torch.ones(1))
+
+
+# ------------------------------------------------------------------------------------------------ sampler
+def test_reverse_diffusion_ode_matches_reference_golden(S, dev):
+    g = golden("rd_ode.npz")
+    sd, plan, blob = plan_for(S, dev, int(g["seed"]))
+    out = plan.reverse_diffusion(blob, _t(g["z"]).to(dev), _t(g["mask"]).to(dev), _t(g["mu"]).to(dev), int(g["n"])).cpu()
+    assert relerr(out, _t(g["out"])) <= REL
+
+
+def test_reverse_diffusion_sde_matches_reference_golden(S, dev):
+    g = golden("rd_sde.npz")
+    sd, plan, blob = plan_for(S, dev, int(g["seed"]))
+    out = plan.reverse_diffusion(blob, _t(g["z"]).to(dev), _t(g["mask"]).to(dev), _t(g["mu"]).to(dev), int(g["n"]),
+                                 noise=_t(g["noise"]).to(dev)).cpu()
+    assert relerr(out, _t(g["out"])) <= REL
+
+
+def test_reverse_diffusion_mel_scale_absolute_tolerance(S, dev):
+    """Mel-scale fixture: terminal noise scaled so the sampled mel stays O(1..10) through the e^5 growth of the
+    untrained reverse ODE -> the north-star's 1e-3 max-abs bound is applied literally."""
+    sd, plan, blob = plan_for(S, dev, 0)
+    inp = O.make_inputs(2, 64, seed=21, temperature=150.0)
+    ref = O.reverse_diffusion(sd, inp["z"], inp["mask"], inp["mu"], 10)
+    out = plan.reverse_diffusion(blob, inp["z"].to(dev), inp["mask"].to(dev), inp["mu"].to(dev), 10).cpu()
+    assert 0.5 < float(ref.abs().max()) < 50
+    assert float((out - ref).abs().max()) <= 1e-3
+
+
+def test_teacher_forced_trajectory(S, dev):
+    """Feed the oracle's own x_t of every step to the HIP estimator (no error growth through the unstable ODE)."""
+    sd, plan, blob = plan_for(S, dev, 0)
+    inp = O.make_inputs(2, 48, seed=5)
+    traj = []
+    O.reverse_diffusion(sd, inp["z"], inp["mask"], inp["mu"], 10, trajectory=traj)
+    h = 1.0 / 10
+    worst = 0.0
+    for i, (xt, est) in enumerate(traj):
+        t = torch.full((2,), np.float32(1.0 - (i + 0.5) * h))
+        got = plan.estimator_forward(blob, xt.to(dev), inp["mask"].to(dev), inp["mu"].to(dev), t.to(dev)).cpu()
+        worst = max(worst, relerr(got, est))
+    assert worst <= REL
+
+
+def test_precision_modes_ordering(S, dev):
+    """plain bf16 (config 3) is looser than bf16x3 but still tracks the oracle; documents both error levels."""
+    sd = O.make_estimator_state(seed=0)
+    inp = O.make_inputs(2, 64, seed=2)
+    t = torch.tensor([0.4, 0.6])
+    ref = O.estimator_forward(sd, inp["z"], inp["mask"], inp["mu"], t)
+    errs = {}
+    for name, prec in (("bf16x3", S.PREC_BF16X3), ("bf16", S.PREC_BF16)):
+        p = S.Plan(precision=prec)
+        out = p.estimator_forward(p.pack(sd, dev), inp["z"].to(dev), inp["mask"].to(dev), inp["mu"].to(dev), t.to(dev)).cpu()
+        errs[name] = relerr(out, ref)
+    assert errs["bf16x3"] <= REL
+    assert errs["bf16x3"] < errs["bf16"] <= 5e-2
+
+
+# ------------------------------------------------------------------------------------------------ full size
+def test_full_size_properties(S, dev):
+    """BASELINE config 2 shape (B=16, 80x1024): size-independent properties instead of a CPU comparison --
+    finite, masked frames exactly zero, run-to-run bit-reproducible, and batch sharding is exact (utterances are
+    independent: B=16 in one call == two calls of B=8)."""
+    sd, plan, blob = plan_for(S, dev, 0)
+    B, T = 16, 1024
+    inp = O.make_inputs(B, T, seed=1234, ragged=True)
+    z, m, mu = inp["z"].to(dev), inp["mask"].to(dev), inp["mu"].to(dev)
+    a = plan.reverse_diffusion(blob, z, m, mu, 2)
+    b = plan.reverse_diffusion(blob, z, m, mu, 2)
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b)
+    assert float((a * (1 - m)).abs().max()) == 0.0
+    lo = plan.reverse_diffusion(blob, z[:8].contiguous(), m[:8].contiguous(), mu[:8].contiguous(), 2)
+    hi = plan.reverse_diffusion(blob, z[8:].contiguous(), m[8:].contiguous(), mu[8:].contiguous(), 2)
+    assert torch.equal(a, torch.cat([lo, hi], 0))
+    # one sample of the big batch against the CPU oracle (B=1 keeps the CPU time to seconds)
+    ref = O.reverse_diffusion(sd, inp["z"][3:4], inp["mask"][3:4], inp["mu"][3:4], 2)
+    assert relerr(a[3:4].cpu(), ref) <= REL
+
+
+# ------------------------------------------------------------------------------------------------ drop-in modules
+def test_diffusion_module_drop_in(S, dev):
+    M = importlib.import_module("speech-backbones_amd.model.diffusion")
+    sd = O.make_estimator_state(seed=11)
+    dec = M.Diffusion(80, 64, 1, 64, 0.05, 20.0, 1000)
+    dec.load_state_dict({"estimator." + k: v for k, v in sd.items()}, strict=True)
+    dec = dec.to(dev).eval()
+    inp = O.make_inputs(2, 40, seed=6)
+    z, m, mu = inp["z"].to(dev), inp["mask"].to(dev), inp["mu"].to(dev)
+    out = dec(z, m, mu, 5).cpu()
+    assert relerr(out, O.reverse_diffusion(sd, inp["z"], inp["mask"], inp["mu"], 5)) <= REL
+    t = torch.tensor([0.3, 0.9])
+    with torch.no_grad():
+        est = dec.estimator(z, m, mu, t.to(dev)).cpu()
+    assert relerr(est, O.estimator_forward(sd, inp["z"], inp["mask"], inp["mu"], t)) <= REL
+    # stoc=True: same RNG stream consumption as the reference (one randn of z's shape per step on z's device)
+    torch.manual_seed(123)
+    s1 = dec(z, m, mu, 3, stoc=True)
+    torch.manual_seed(123)
+    noise = torch.stack([torch.randn(z.shape, dtype=z.dtype, device=z.device) for _ in range(3)])
+    ref = O.reverse_diffusion(sd, inp["z"], inp["mask"], inp["mu"], 3, stoc=True, noise=noise.cpu())
+    assert relerr(s1.cpu(), ref) <= REL
+    # weights changed -> packed blob is rebuilt
+    with torch.no_grad():
+        dec.estimator.final_conv.bias.add_(1.0)
+        est2 = dec.estimator(z, m, mu, t.to(dev)).cpu()
+    assert float((est2 - est).abs().max()) > 0.5
+
+
+def test_gradtts_forward_drop_in(S, dev):
+    """GradTTS.forward (tts.py:50-99) on the GPU: alignment indices bit-exact given the model's own durations,
+    decoder output vs the oracle run on the same (mu_y, z), and the reference's attn-slicing quirk."""
+    M = importlib.import_module("speech-backbones_amd.model")
+    torch.manual_seed(0)
+    model = M.GradTTS(149, 1, 64, 192, 768, 256, 2, 6, 3, 0.1, 4, 80, 64, 0.05, 20.0, 1000)
+    sd = O.make_estimator_state(seed=2)
+    model.decoder.estimator.load_state_dict(sd, strict=True)
+    with torch.no_grad():                      # zero-init prenet/proj would give trivial durations
+        model.encoder.proj_w.proj.bias.fill_(1.2)
+    model = model.to(dev).eval()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randint(0, 149, (2, 23), generator=g)
+    xl = torch.tensor([23, 15])
+    torch.manual_seed(77)
+    enc, dec_out, attn = model(x.to(dev), xl.to(dev), n_timesteps=4, temperature=1.5, length_scale=0.91)
+    # re-derive the host-side pieces from the model's own encoder outputs (teacher-forced durations)
+    with torch.no_grad():
+        mu_x, logw, x_mask = model.encoder(x.to(dev), xl.to(dev), None)
+    w_ceil = (torch.ceil(torch.exp(logw) * x_mask) * 0.91).cpu()
+    y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
+    y_max = int(y_lengths.max())
+    y_max_ = O.fix_len_compatibility(y_max)
+    y_mask = O.sequence_mask(y_lengths, y_max_).unsqueeze(1).float()
+    attn_mask = x_mask.cpu().unsqueeze(-1) * y_mask.unsqueeze(2)
+    path = O.generate_path(w_ceil.squeeze(1), attn_mask.squeeze(1)).unsqueeze(1)
+    assert torch.equal(attn.cpu(), path[:, :, :y_max])                  # bit-exact alignment (+ t_x-axis slice quirk)
+    mu_y = torch.matmul(path.squeeze(1).transpose(1, 2), mu_x.cpu().transpose(1, 2)).transpose(1, 2)
+    assert relerr(enc.cpu(), mu_y[:, :, :y_max]) <= 1e-5
+    torch.manual_seed(77)
+    z = mu_y + torch.randn(mu_y.shape, device=dev).cpu() / 1.5
+    ref = O.reverse_diffusion(sd, z, y_mask, mu_y, 4)[:, :, :y_max]
+    assert dec_out.shape == ref.shape
+    assert relerr(dec_out.cpu(), ref) <= REL
+
+
+def test_monotonic_align_module_on_gpu(S, dev):
+    MA = importlib.import_module("speech-backbones_amd.model.monotonic_align")
+    g = golden("mas.npz")
+    path = MA.maximum_path(_t(g["value"]).to(dev), _t(g["mask"]).float().to(dev))
+    assert path.dtype == torch.float32 and path.is_cuda
+    assert torch.equal(path.cpu().to(torch.uint8), _t(g["path"]))
