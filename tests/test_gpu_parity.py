@@ -184,11 +184,17 @@ def test_reverse_diffusion_sde_matches_reference_golden(S, dev):
 def test_reverse_diffusion_mel_scale_absolute_tolerance(S, dev):
     """Mel-scale fixture: terminal noise scaled so the sampled mel stays O(1..10) through the e^5 growth of the
     untrained reverse ODE -> the north-star's 1e-3 max-abs bound is applied literally."""
-    sd, plan, blob = plan_for(S, dev, 0)
+    sd = dict(O.make_estimator_state(seed=0))
+    # an untrained score net of O(1) output drives x_t to |x| ~ 60; scaling its last layer (like a score near
+    # convergence) keeps the sample in the log-mel range (|x| < 10)
+    sd["final_conv.weight"] = sd["final_conv.weight"] * 0.1
+    sd["final_conv.bias"] = sd["final_conv.bias"] * 0.1
+    plan = S.Plan()
+    blob = plan.pack(sd, dev)
     inp = O.make_inputs(2, 64, seed=21, temperature=150.0)
     ref = O.reverse_diffusion(sd, inp["z"], inp["mask"], inp["mu"], 10)
     out = plan.reverse_diffusion(blob, inp["z"].to(dev), inp["mask"].to(dev), inp["mu"].to(dev), 10).cpu()
-    assert 0.5 < float(ref.abs().max()) < 50
+    assert 1.0 < float(ref.abs().max()) < 15
     assert float((out - ref).abs().max()) <= 1e-3
 
 
@@ -303,7 +309,10 @@ def test_gradtts_forward_drop_in(S, dev):
     mu_y = torch.matmul(path.squeeze(1).transpose(1, 2), mu_x.cpu().transpose(1, 2)).transpose(1, 2)
     assert relerr(enc.cpu(), mu_y[:, :, :y_max]) <= 1e-5
     torch.manual_seed(77)
-    z = mu_y + torch.randn(mu_y.shape, device=dev).cpu() / 1.5
+    # tts.py:94 draws randn_like(mu_y) where mu_y is a transposed (non-contiguous) [B,T,80] buffer: the Philox
+    # stream fills memory order, so reproduce the strides before drawing
+    tmpl = torch.empty(mu_y.shape[0], mu_y.shape[2], mu_y.shape[1], device=dev).transpose(1, 2)
+    z = mu_y + torch.randn_like(tmpl).cpu() / 1.5
     ref = O.reverse_diffusion(sd, z, y_mask, mu_y, 4)[:, :, :y_max]
     assert dec_out.shape == ref.shape
     assert relerr(dec_out.cpu(), ref) <= REL

@@ -12,7 +12,7 @@ timeout 600 python bench.py --steps 3 --warmup 1 > gpurun_out/bench_$TAG.json 2>
 echo "bench rc=$?"
 cat gpurun_out/bench_$TAG.json; tail -20 gpurun_out/bench_$TAG.stderr
 if [ "${SKIP_PROF:-0}" != "1" ]; then
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o prof -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/prof_$TAG.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o prof -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/prof_$TAG.log 2>&1)
   echo "rocprof rc=$?"
   find /tmp/prof_$TAG -name "*stats*" | head
   for f in $(find /tmp/prof_$TAG -name "*kernel_stats*.csv"); do cp $f gpurun_out/rocprof_kernel_stats_$TAG.csv; done
