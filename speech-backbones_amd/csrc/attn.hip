@@ -214,38 +214,71 @@ hipError_t launch_attn_ctx(const float *x, const unsigned char *wkv, float *part
 }
 
 // ------------------------------------------------------------------------------------------------ attn_merge
-// grid (4 heads, B).  ctxn[b][h][d][e] = sum_i ctx_i[d][e] exp(m_i[d]-M[d]) / sum_i Z_i[d] exp(m_i[d]-M[d])
-__global__ void attn_merge_kernel(const float *__restrict__ partials, float *__restrict__ ctxn, int nrec) {
-    __shared__ float s_M[32], s_Zi[32];
+// grid (4 heads, B), 1024 threads.  ctxn[b][h][d][e] = sum_i ctx_i[d][e] w_i[d] / sum_i Z_i[d] w_i[d],
+// w_i[d] = exp(m_i[d] - M[d]), M[d] = max_i m_i[d].  Fixed reduction order => bit-reproducible.
+__global__ __launch_bounds__(1024) void attn_merge_kernel(const float *__restrict__ partials, float *__restrict__ ctxn,
+                                                           int nrec) {
+    extern __shared__ float sm[];
+    float *s_w = sm;                        // [nrec][32]
+    float *s_red = sm + (size_t)nrec * 32;  // [32][32]
+    float *s_M = s_red + 1024;              // [32]
+    float *s_Zi = s_M + 32;                 // [32]
     const int head = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int d = tid & 31, g = tid >> 5;
     const float *rec = partials + ((size_t)b * 4 + head) * nrec * ATTN_REC;
     const float NEG_INF = -__builtin_inff();
-    if (tid < 32) {
+    float mx = NEG_INF;
+    for (int i = g; i < nrec; i += 32) mx = fmaxf(mx, rec[(size_t)i * ATTN_REC + d]);
+    s_red[g * 32 + d] = mx;
+    __syncthreads();
+    if (g == 0) {
         float M = NEG_INF;
-        for (int i = 0; i < nrec; ++i) M = fmaxf(M, rec[(size_t)i * ATTN_REC + tid]);
-        float Z = 0.f;
-        for (int i = 0; i < nrec; ++i) {
-            const float mi = rec[(size_t)i * ATTN_REC + tid];
-            if (mi != NEG_INF) Z += rec[(size_t)i * ATTN_REC + 32 + tid] * expf(mi - M);
-        }
-        s_M[tid] = M;
-        s_Zi[tid] = 1.0f / Z;
+        for (int k = 0; k < 32; ++k) M = fmaxf(M, s_red[k * 32 + d]);
+        s_M[d] = M;
     }
     __syncthreads();
-    for (int idx = tid; idx < 1024; idx += 256) {
-        const int d = idx >> 5;
-        const float M = s_M[d];
-        float acc = 0.f;
-        for (int i = 0; i < nrec; ++i) {
-            const float mi = rec[(size_t)i * ATTN_REC + d];
-            if (mi != NEG_INF) acc += rec[(size_t)i * ATTN_REC + 64 + idx] * expf(mi - M);
-        }
-        ctxn[(((size_t)b * 4 + head) * 1024) + idx] = acc * s_Zi[d];
+    const float M = s_M[d];
+    float zz = 0.f;
+    for (int i = g; i < nrec; i += 32) {
+        const float mi = rec[(size_t)i * ATTN_REC + d];
+        const float w = (mi == NEG_INF) ? 0.f : expf(mi - M);
+        s_w[i * 32 + d] = w;
+        zz += rec[(size_t)i * ATTN_REC + 32 + d] * w;
     }
+    __syncthreads();          // everyone is done reading the maxima in s_red
+    s_red[g * 32 + d] = zz;
+    __syncthreads();
+    if (g == 0) {
+        float Z = 0.f;
+        for (int k = 0; k < 32; ++k) Z += s_red[k * 32 + d];
+        s_Zi[d] = 1.0f / Z;
+    }
+    __syncthreads();
+    const int dd = tid >> 5;                // row of ctx entry `tid` (entry = dd*32 + e)
+    float acc = 0.f;
+    const float *cp = rec + 64 + tid;
+    int i = 0;
+    for (; i + 4 <= nrec; i += 4) {
+        const float c0 = cp[(size_t)(i + 0) * ATTN_REC], c1 = cp[(size_t)(i + 1) * ATTN_REC];
+        const float c2 = cp[(size_t)(i + 2) * ATTN_REC], c3 = cp[(size_t)(i + 3) * ATTN_REC];
+        acc = fmaf(c0, s_w[(i + 0) * 32 + dd], acc);
+        acc = fmaf(c1, s_w[(i + 1) * 32 + dd], acc);
+        acc = fmaf(c2, s_w[(i + 2) * 32 + dd], acc);
+        acc = fmaf(c3, s_w[(i + 3) * 32 + dd], acc);
+    }
+    for (; i < nrec; ++i) acc = fmaf(cp[(size_t)i * ATTN_REC], s_w[i * 32 + dd], acc);
+    ctxn[(((size_t)b * 4 + head) * 1024) + tid] = acc * s_Zi[dd];
 }
 
 hipError_t launch_attn_merge(const float *partials, float *ctxn, int B, int nrec, hipStream_t st) {
-    hipLaunchKernelGGL(attn_merge_kernel, dim3(4, B), dim3(256), 0, st, partials, ctxn, nrec);
+    const size_t smem = ((size_t)nrec * 32 + 1024 + 64) * sizeof(float);
+    if (smem > 160 * 1024) return hipErrorInvalidValue;
+    if (smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_merge_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(attn_merge_kernel, dim3(4, B), dim3(1024), smem, st, partials, ctxn, nrec);
     return hipGetLastError();
 }
 
@@ -254,7 +287,7 @@ hipError_t launch_attn_merge(const float *partials, float *ctxn, int B, int nrec
 __global__ void attn_fold_kernel(const float *__restrict__ ctxn, const float *__restrict__ wq,
                                  const float *__restrict__ wout, const float *__restrict__ bout,
                                  const float *__restrict__ g, unsigned char *__restrict__ wpk, size_t wpk_bstride,
-                                 float *__restrict__ biasb, int C, int MT) {
+                                 float *__restrict__ biasb, int C, int MT, int nkg) {
     __shared__ float s_U[16][128];
     const int co0 = blockIdx.x * 16, b = blockIdx.y, tid = threadIdx.x;
     const float *cb = ctxn + (size_t)b * 4096;
@@ -280,13 +313,13 @@ __global__ void attn_fold_kernel(const float *__restrict__ ctxn, const float *__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = fmaf(s_U[r][j], q, acc[r]);
         }
-        const int chunk = ci >> 4, kg = (ci >> 3) & 1, i = ci & 7;
+        const int chunk = ci / (8 * nkg), kg = (ci >> 3) % nkg, i = ci & 7;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + r, cot = co / MT, m = co % MT;
             const size_t blk = (size_t)chunk * ncot + cot;             // CONV_P1: one stage, one tap
-            const size_t e_hi = blk * ((size_t)MT * 32) + ((size_t)(0 * 2 + kg) * MT + m) * 8 + i;
-            const size_t e_lo = blk * ((size_t)MT * 32) + ((size_t)(1 * 2 + kg) * MT + m) * 8 + i;
+            const size_t e_hi = blk * ((size_t)MT * 16 * nkg) + ((size_t)(0 * nkg + kg) * MT + m) * 8 + i;
+            const size_t e_lo = blk * ((size_t)MT * 16 * nkg) + ((size_t)(1 * nkg + kg) * MT + m) * 8 + i;
             __bf16 hi, lo;
             split_bf16(acc[r] * gv, hi, lo);
             wp[e_hi] = hi;
@@ -299,9 +332,10 @@ __global__ void attn_fold_kernel(const float *__restrict__ ctxn, const float *__
 hipError_t launch_attn_fold(const float *ctxn, const float *wq, const float *wout, const float *bout, const float *g,
                             unsigned char *wpk, size_t wpk_bstride, float *biasb, int B, int C, hipStream_t st) {
     if (C % 16 != 0) return hipErrorInvalidValue;
-    ConvGeom geom = conv_geom(CONV_P1, C);
+    ConvGeom geom = conv_geom(CONV_P1, C, C);
+    if (C % (16 * geom.kch) != 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(attn_fold_kernel, dim3(C / 16, B), dim3(256), 0, st, ctxn, wq, wout, bout, g, wpk, wpk_bstride,
-                       biasb, C, geom.MT);
+                       biasb, C, geom.MT, 2 * geom.kch);
     return hipGetLastError();
 }
 

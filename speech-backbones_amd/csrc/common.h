@@ -60,7 +60,7 @@ struct ConvArgs {
     const float *src1;
     int c0, c1;
     int cin;            // c0 + c1
-    int nchunk;         // ceil(cin / 16)
+    int nchunk;         // ceil(cin / (16 * kch))   (set by launch_conv)
     int B, Hin, Win, Hout, Wout;
     const float *mask;  // [B][T] (level-0 mask); level-l column j is mask[b][j << lvl]
     int T;
@@ -91,25 +91,27 @@ struct ConvArgs {
 struct ConvGeom {
     int MT;     // output channels per workgroup
     int TR;     // output rows per workgroup (32 columns always)
-    int nst;    // weight stages per 16-channel chunk
+    int nst;    // weight stages per chunk
     int tps;    // taps per stage
+    int kch;    // 16-channel MFMA k-steps per chunk (chunk = 16 * kch input channels)
 };
 // host helper: how a layer is tiled (must match the template instantiations in conv_mfma.hip)
-static inline ConvGeom conv_geom(int mode, int cout) {
+static inline ConvGeom conv_geom(int mode, int cin, int cout) {
     ConvGeom g;
     bool wide = cout > 64;
     g.MT = wide ? 128 : 64;
+    g.kch = (mode == CONV_DN || cin <= 16) ? 1 : 2;
     if (mode == CONV_DN) { g.TR = 4; g.nst = 3; g.tps = 3; }
     else if (mode == CONV_UP) { g.TR = wide ? 4 : 8; g.nst = 2; g.tps = 2; }
     else if (mode == CONV_P1) { g.TR = wide ? 4 : 8; g.nst = 1; g.tps = 1; }
     else { g.TR = wide ? 4 : 8; g.nst = 3; g.tps = 3; }
     return g;
 }
-static inline size_t conv_wblock_bytes(const ConvGeom &g) { return (size_t)g.tps * g.MT * 64; }
+static inline size_t conv_wblock_bytes(const ConvGeom &g) { return (size_t)g.tps * g.MT * 64 * g.kch; }
 // packed bytes of one conv's weights: [phase][chunk][stage][cout tile] blocks
 static inline size_t conv_packed_bytes(int mode, int cin, int cout) {
-    ConvGeom g = conv_geom(mode, cout);
-    size_t nchunk = (cin + 15) / 16, ncot = (cout + g.MT - 1) / g.MT;
+    ConvGeom g = conv_geom(mode, cin, cout);
+    size_t nchunk = (cin + 16 * g.kch - 1) / (16 * g.kch), ncot = (cout + g.MT - 1) / g.MT;
     size_t phases = (mode == CONV_UP) ? 4 : 1;
     return phases * nchunk * g.nst * ncot * conv_wblock_bytes(g);
 }

@@ -9,10 +9,10 @@
 // Data layout: activations stay in the reference's NCHW fp32 layout ([B,C,mel-bin,frame], frame fastest), so
 // global loads are coalesced along the mel-frame axis.  GEMM view per workgroup:
 //     D[cout (MT)][pixel (TR x 32)] = sum_{tap, cin} W[cout][cin, tap] * X[cin][pixel + tap]
-// with cin walked in chunks of 16 (= K of v_mfma_f32_32x32x16_bf16).  Per chunk the workgroup stages the halo
+// with cin walked in chunks of 16*KCH (K of v_mfma_f32_32x32x16_bf16 is 16; KCH k-steps per chunk).  Per chunk the workgroup stages the halo
 // tile of 16 input channels into LDS *through registers*, applying the producer's epilogue on the way
 // (GroupNorm affine + Mish + mask + time bias: "apply-on-load", so normalised tensors never touch HBM) and
-// splitting fp32 into bf16 hi/lo.  LDS image: [kgroup(2)][pixel][8 channels] x {hi, lo}: one 16-byte slot per
+// splitting fp32 into bf16 hi/lo.  LDS image: [kgroup(2*KCH)][pixel][8 channels] x {hi, lo}: one 16-byte slot per
 // (pixel, 8-channel group) -> both the staging ds_write_b128 and the MFMA B-fragment ds_read_b128 are
 // conflict-free, and a tap is just a pixel offset.  Weights are pre-packed on the device (pack.hip) in
 // exactly the LDS image order, one contiguous block per (chunk, stage, cout tile).
@@ -25,7 +25,7 @@
 
 namespace gtts {
 
-template <int MODE, int WM, int WN, int MF>
+template <int MODE, int WM, int WN, int MF, int KCH>
 struct ConvCfg {
     static constexpr int MT = WM * MF * 32;
     static constexpr int TR = WN * 2;
@@ -35,30 +35,31 @@ struct ConvCfg {
     static constexpr int HR = MODE == CONV_P1 ? TR : (MODE == CONV_DN ? 2 * TR + 1 : TR + 2);
     static constexpr int HC = MODE == CONV_P1 ? TC : (MODE == CONV_DN ? 2 * TC + 1 : TC + 2);
     static constexpr int NPIX = HR * HC;
-    static constexpr int AITER = (2 * NPIX + 255) / 256;   // (pixel, kgroup) staging items per thread
-    static constexpr int WBLK16 = TPS * MT * 4;            // 16-byte units per weight block
+    static constexpr int NKG = 2 * KCH;                     // 8-channel groups per chunk (chunk = 16*KCH channels)
+    static constexpr int AITER = (NKG * NPIX + 255) / 256;  // (pixel, kgroup) staging items per thread
+    static constexpr int WBLK16 = TPS * MT * 2 * NKG;       // 16-byte units per weight block
     static constexpr int WITER = WBLK16 / 256;
     static_assert(WBLK16 % 256 == 0, "weight block must be a whole number of 256 x 16-byte rows");
 };
 
-static inline size_t conv_smem_bytes(int npix, int wblk16, int cin) {
-    size_t cpad = (size_t)((cin + 15) / 16) * 16;
-    return (size_t)npix * 2 * 16 * 2 + (size_t)wblk16 * 16 + 3 * cpad * 4 + 4 * 2 * 4 * 2 * 4;
+static inline size_t conv_smem_bytes(int npix, int nkg, int wblk16, int cin, int pro) {
+    size_t cpad = (size_t)((cin + 8 * nkg - 1) / (8 * nkg)) * 8 * nkg;
+    return (size_t)npix * nkg * 16 * 2 + (size_t)wblk16 * 16 + (pro == PRO_GN ? 3 * cpad * 4 : 0) + 4 * 2 * 4 * 2 * 4;
 }
 
-template <int MODE, int WM, int WN, int MF>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
-    using C = ConvCfg<MODE, WM, WN, MF>;
-    constexpr int MT = C::MT, TR = C::TR, TC = C::TC, NST = C::NST, TPS = C::TPS;
+template <int MODE, int WM, int WN, int MF, int KCH>
+__global__ __launch_bounds__(256, (MODE == CONV_P1 && !(WM == 1 && KCH == 2)) ? 3 : 2) void conv_mfma_kernel(const ConvArgs a) {
+    using C = ConvCfg<MODE, WM, WN, MF, KCH>;
+    constexpr int MT = C::MT, TR = C::TR, TC = C::TC, NST = C::NST, TPS = C::TPS, NKG = C::NKG;
     constexpr int HC = C::HC, NPIX = C::NPIX, AITER = C::AITER, WBLK16 = C::WBLK16, WITER = C::WITER;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32x4 *s_ah = reinterpret_cast<u32x4 *>(smem);      // [2][NPIX]  hi
-    u32x4 *s_al = s_ah + 2 * NPIX;                      // [2][NPIX]  lo
-    u32x4 *s_w = s_al + 2 * NPIX;                       // [split][tap][kg][MT]
-    const int cpad = a.nchunk * 16;
+    u32x4 *s_ah = reinterpret_cast<u32x4 *>(smem);      // [NKG][NPIX]  hi
+    u32x4 *s_al = s_ah + NKG * NPIX;                    // [NKG][NPIX]  lo
+    u32x4 *s_w = s_al + NKG * NPIX;                     // [split][tap][kg][MT]
+    const int cpad = a.nchunk * 8 * NKG;
     float *s_par = reinterpret_cast<float *>(s_w + WBLK16);   // [3][cpad]: scale, shift, time bias
-    float *s_red = s_par + 3 * cpad;                          // [4 waves][MF][4 slots][2]
+    float *s_red = s_par + (a.pro == PRO_GN ? 3 * cpad : 0);  // [4 waves][MF][4 slots][2]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kg_l = lane >> 5;
@@ -87,13 +88,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     // ---- staging items: geometry is chunk-invariant
     int it_goff[AITER];     // offset inside a channel plane, -1 = outside the image / no item
     int it_lds[AITER];      // destination slot in s_ah / s_al
-    int it_kg8[AITER];      // 0 or 8: first channel of the item inside the chunk
+    int it_kg8[AITER];      // first channel of the item inside the chunk (kgroup * 8)
     float it_m[AITER];      // mask value at the item's frame (0 outside the image)
 #pragma unroll
     for (int it = 0; it < AITER; ++it) {
         int idx = tid + it * 256;
-        bool has = idx < 2 * NPIX;
-        int kg = (idx >= NPIX) ? 1 : 0;
+        bool has = idx < NKG * NPIX;
+        int kg = idx / NPIX;
         int p = idx - kg * NPIX;
         int pr = p / HC, pc = p - pr * HC;
         int gy = iy0 + pr, gx = ix0 + pc;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     auto load_act = [&](int chunk) {
 #pragma unroll
         for (int it = 0; it < AITER; ++it) {
-            int cbase = chunk * 16 + it_kg8[it];
+            int cbase = chunk * (8 * NKG) + it_kg8[it];
             const float *src;
             int cloc, ctot;
             if (cbase < a.c0) { src = a.src0; cloc = cbase; ctot = a.c0; }
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         for (int it = 0; it < AITER; ++it) {
             if (it_lds[it] >= 0) {
                 const float m = it_m[it];
-                const int cb = chunk * 16 + it_kg8[it];
+                const int cb = chunk * (8 * NKG) + it_kg8[it];
                 bf16x8 vh, vl;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -182,44 +183,52 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < WITER; ++i) s_w[tid + i * 256] = wregs[i];
             __syncthreads();
-            // ---- prefetch the next weight block / activation chunk behind this stage's MFMAs
+            // ---- prefetch behind the MFMAs: next weight block (one stage ahead) and, as early as the staging
+            // registers are free again, the next activation chunk (a whole chunk of MFMAs ahead)
             if (stage + 1 < NST) load_w(chunk, stage + 1);
-            else if (chunk + 1 < a.nchunk) { load_w(chunk + 1, 0); load_act(chunk + 1); }
+            else if (chunk + 1 < a.nchunk) load_w(chunk + 1, 0);
+            if (stage == 0 && chunk + 1 < a.nchunk) load_act(chunk + 1);
 
 #pragma unroll
             for (int j = 0; j < TPS; ++j) {
-                bf16x8 wh[MF], wl[MF], xh[2], xl[2];
-#pragma unroll
-                for (int mi = 0; mi < MF; ++mi) {
-                    int wi = (j * 2 + kg_l) * MT + m0 + mi * 32 + l31;
-                    wh[mi] = *reinterpret_cast<const bf16x8 *>(&s_w[wi]);
-                    wl[mi] = *reinterpret_cast<const bf16x8 *>(&s_w[wi + TPS * 2 * MT]);
-                }
+                int po[2];
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
                     const int r = wn * 2 + ni;
-                    int po;
-                    if (MODE == CONV_C3) po = (r + stage) * HC + j;
-                    else if (MODE == CONV_DN) po = (2 * r + stage) * HC + (j == 1 ? 33 : (j >> 1));
+                    if (MODE == CONV_C3) po[ni] = (r + stage) * HC + j;
+                    else if (MODE == CONV_DN) po[ni] = (2 * r + stage) * HC + (j == 1 ? 33 : (j >> 1));
                     else if (MODE == CONV_UP) {
                         int dy = ph_y == 0 ? (stage == 0 ? 0 : -1) : (stage == 0 ? 1 : 0);
                         int dx = ph_x == 0 ? (j == 0 ? 0 : -1) : (j == 0 ? 1 : 0);
-                        po = (r + 1 + dy) * HC + 1 + dx;
-                    } else po = r * HC;
-                    int xi = kg_l * NPIX + po + l31;
-                    xh[ni] = *reinterpret_cast<const bf16x8 *>(&s_ah[xi]);
-                    xl[ni] = *reinterpret_cast<const bf16x8 *>(&s_al[xi]);
+                        po[ni] = (r + 1 + dy) * HC + 1 + dx;
+                    } else po[ni] = r * HC;
                 }
 #pragma unroll
-                for (int mi = 0; mi < MF; ++mi)
+                for (int kc = 0; kc < KCH; ++kc) {
+                    bf16x8 wh[MF], wl[MF], xh[2], xl[2];
+#pragma unroll
+                    for (int mi = 0; mi < MF; ++mi) {
+                        int wi = (j * NKG + kc * 2 + kg_l) * MT + m0 + mi * 32 + l31;
+                        wh[mi] = *reinterpret_cast<const bf16x8 *>(&s_w[wi]);
+                        wl[mi] = *reinterpret_cast<const bf16x8 *>(&s_w[wi + TPS * NKG * MT]);
+                    }
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni) {
-                        if (lo_on) {
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[mi], xh[ni], acc[mi][ni], 0, 0, 0);
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[mi], xl[ni], acc[mi][ni], 0, 0, 0);
-                        }
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[mi], xh[ni], acc[mi][ni], 0, 0, 0);
+                        int xi = (kc * 2 + kg_l) * NPIX + po[ni] + l31;
+                        xh[ni] = *reinterpret_cast<const bf16x8 *>(&s_ah[xi]);
+                        xl[ni] = *reinterpret_cast<const bf16x8 *>(&s_al[xi]);
                     }
+#pragma unroll
+                    for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            if (lo_on) {
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[mi], xh[ni], acc[mi][ni], 0, 0, 0);
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[mi], xl[ni], acc[mi][ni], 0, 0, 0);
+                            }
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[mi], xh[ni], acc[mi][ni], 0, 0, 0);
+                        }
+                }
             }
         }
     }
@@ -311,41 +320,51 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     }
 }
 
-template <int MODE, int WM, int WN, int MF>
+template <int MODE, int WM, int WN, int MF, int KCH>
 static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
-    using C = ConvCfg<MODE, WM, WN, MF>;
+    using C = ConvCfg<MODE, WM, WN, MF, KCH>;
     ConvArgs a = a_in;
+    a.nchunk = (a.cin + 16 * KCH - 1) / (16 * KCH);
     const int th = (MODE == CONV_UP) ? a.Hin : a.Hout;   // tile space: input resolution for UP
     const int tw = (MODE == CONV_UP) ? a.Win : a.Wout;
     a.tiles_x = (tw + C::TC - 1) / C::TC;
     a.tiles_y = (th + C::TR - 1) / C::TR;
     const int ncot = (a.cout + C::MT - 1) / C::MT;
     dim3 grid(a.tiles_x * a.tiles_y, ncot * (MODE == CONV_UP ? 4 : 1), a.B);
-    size_t smem = conv_smem_bytes(C::NPIX, C::WBLK16, a.cin);
+    size_t smem = conv_smem_bytes(C::NPIX, C::NKG, C::WBLK16, a.cin, a.pro);
     static size_t attr_set = 0;
     if (smem > attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<MODE, WM, WN, MF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<MODE, WM, WN, MF, KCH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr_set = smem;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, MF>), grid, dim3(256), smem, st, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, MF, KCH>), grid, dim3(256), smem, st, a);
     return hipGetLastError();
 }
 
 // number of GroupNorm partial slots per sample that EPI_STATS writes for this layer
 int conv_nparts(int mode, int cout, int Hout, int Wout) {
-    ConvGeom g = conv_geom(mode, cout);
+    ConvGeom g = conv_geom(mode, 64, cout);
     return ((Wout + 31) / 32) * ((Hout + g.TR - 1) / g.TR);
 }
 
+// template instances; must agree with conv_geom() in common.h
 hipError_t launch_conv(int mode, const ConvArgs &a, hipStream_t st) {
     const bool wide = a.cout > 64;
+    const bool k1 = a.cin <= 16;
     switch (mode) {
-        case CONV_C3: return wide ? launch_cfg<CONV_C3, 2, 2, 2>(a, st) : launch_cfg<CONV_C3, 1, 4, 2>(a, st);
-        case CONV_DN: return wide ? launch_cfg<CONV_DN, 2, 2, 2>(a, st) : launch_cfg<CONV_DN, 2, 2, 1>(a, st);
-        case CONV_UP: return wide ? launch_cfg<CONV_UP, 2, 2, 2>(a, st) : launch_cfg<CONV_UP, 1, 4, 2>(a, st);
-        case CONV_P1: return wide ? launch_cfg<CONV_P1, 2, 2, 2>(a, st) : launch_cfg<CONV_P1, 1, 4, 2>(a, st);
+        case CONV_C3:
+            if (wide) return k1 ? launch_cfg<CONV_C3, 2, 2, 2, 1>(a, st) : launch_cfg<CONV_C3, 2, 2, 2, 2>(a, st);
+            return k1 ? launch_cfg<CONV_C3, 1, 4, 2, 1>(a, st) : launch_cfg<CONV_C3, 1, 4, 2, 2>(a, st);
+        case CONV_DN:
+            return wide ? launch_cfg<CONV_DN, 2, 2, 2, 1>(a, st) : launch_cfg<CONV_DN, 2, 2, 1, 1>(a, st);
+        case CONV_UP:
+            if (wide) return k1 ? launch_cfg<CONV_UP, 2, 2, 2, 1>(a, st) : launch_cfg<CONV_UP, 2, 2, 2, 2>(a, st);
+            return k1 ? launch_cfg<CONV_UP, 1, 4, 2, 1>(a, st) : launch_cfg<CONV_UP, 1, 4, 2, 2>(a, st);
+        case CONV_P1:
+            if (wide) return k1 ? launch_cfg<CONV_P1, 2, 2, 2, 1>(a, st) : launch_cfg<CONV_P1, 2, 2, 2, 2>(a, st);
+            return k1 ? launch_cfg<CONV_P1, 1, 4, 2, 1>(a, st) : launch_cfg<CONV_P1, 1, 4, 2, 2>(a, st);
     }
     return hipErrorInvalidValue;
 }

@@ -2,7 +2,7 @@
 //
 // Convolution weights become bf16 (hi, lo) pairs in MFMA-fragment order, one contiguous block per
 // (phase, 16-channel chunk, stage, cout tile); inside a block the order is the LDS image of conv_mfma.hip:
-//     [split: hi|lo][tap][kgroup 0|1][cout-in-tile MT][8 channels]
+//     [split: hi|lo][tap][kgroup 0..2*kch-1][cout-in-tile MT][8 channels]      (chunk = 16*kch input channels)
 // Source layouts are the reference's state_dict layouts:
 //   Conv2d          [cout][cin][kh][kw]        (diffusion.py:33,52,70,87-88)
 //   ConvTranspose2d [cin][cout][4][4]          (diffusion.py:24)
@@ -12,20 +12,20 @@
 namespace gtts {
 
 __global__ void pack_conv_kernel(const float *__restrict__ w, __bf16 *__restrict__ dst, int mode, int cin, int cout,
-                                 int MT, int nst, int tps, int nchunk, int ncot, size_t total) {
+                                 int MT, int nst, int tps, int nchunk, int ncot, int nkg, size_t total) {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;   // one thread per (hi, lo) element pair
     if (t >= total) return;
     // decode t -> (phase, chunk, stage, cot, tap, kg, m, i)
     size_t r = t;
     const int i = r % 8; r /= 8;
     const int m = r % MT; r /= MT;
-    const int kg = r % 2; r /= 2;
+    const int kg = r % nkg; r /= nkg;
     const int tap = r % tps; r /= tps;
     const int cot = r % ncot; r /= ncot;
     const int stage = r % nst; r /= nst;
     const int chunk = r % nchunk; r /= nchunk;
     const int phase = (int)r;
-    const int ci = chunk * 16 + kg * 8 + i;
+    const int ci = chunk * 8 * nkg + kg * 8 + i;
     const int co = cot * MT + m;
     float v = 0.f;
     if (ci < cin && co < cout) {
@@ -43,20 +43,21 @@ __global__ void pack_conv_kernel(const float *__restrict__ w, __bf16 *__restrict
     __bf16 hi, lo;
     split_bf16(v, hi, lo);
     const size_t blk = (((size_t)phase * nchunk + chunk) * nst + stage) * ncot + cot;
-    const size_t blk_elems = (size_t)tps * MT * 32;                          // bf16 elements per block
-    const size_t e_hi = blk * blk_elems + (((size_t)(0 * tps + tap) * 2 + kg) * MT + m) * 8 + i;
-    const size_t e_lo = blk * blk_elems + (((size_t)(1 * tps + tap) * 2 + kg) * MT + m) * 8 + i;
+    const size_t blk_elems = (size_t)tps * MT * 16 * nkg;                    // bf16 elements per block
+    const size_t e_hi = blk * blk_elems + (((size_t)(0 * tps + tap) * nkg + kg) * MT + m) * 8 + i;
+    const size_t e_lo = blk * blk_elems + (((size_t)(1 * tps + tap) * nkg + kg) * MT + m) * 8 + i;
     dst[e_hi] = hi;
     dst[e_lo] = lo;
 }
 
 hipError_t launch_pack_conv(int mode, const float *w, unsigned char *dst, int cin, int cout, hipStream_t st) {
-    ConvGeom g = conv_geom(mode, cout);
-    const int nchunk = (cin + 15) / 16, ncot = (cout + g.MT - 1) / g.MT;
+    ConvGeom g = conv_geom(mode, cin, cout);
+    const int nkg = 2 * g.kch;
+    const int nchunk = (cin + 8 * nkg - 1) / (8 * nkg), ncot = (cout + g.MT - 1) / g.MT;
     const int phases = mode == CONV_UP ? 4 : 1;
-    const size_t total = (size_t)phases * nchunk * g.nst * ncot * g.tps * 2 * g.MT * 8;
+    const size_t total = (size_t)phases * nchunk * g.nst * ncot * g.tps * nkg * g.MT * 8;
     hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w,
-                       reinterpret_cast<__bf16 *>(dst), mode, cin, cout, g.MT, g.nst, g.tps, nchunk, ncot, total);
+                       reinterpret_cast<__bf16 *>(dst), mode, cin, cout, g.MT, g.nst, g.tps, nchunk, ncot, nkg, total);
     return hipGetLastError();
 }
 

@@ -600,7 +600,7 @@ static int run_ops(const RunCtx &c) {
                 memset(&a, 0, sizeof(a));
                 a.src0 = tptr(c, o.src0);
                 a.src1 = o.src1 >= 0 ? tptr(c, o.src1) : a.src0;
-                a.c0 = o.c0; a.c1 = o.c1; a.cin = o.c0 + o.c1; a.nchunk = (a.cin + 15) / 16;
+                a.c0 = o.c0; a.c1 = o.c1; a.cin = o.c0 + o.c1; a.nchunk = 0;
                 a.B = c.B;
                 a.Hin = F >> o.lvl_in; a.Win = c.T >> o.lvl_in;
                 a.Hout = F >> o.lvl_out; a.Wout = c.T >> o.lvl_out;
@@ -789,14 +789,15 @@ extern "C" int gtts_mas_maximum_path(const float *value, const float *mask, cons
 
 
 // ------------------------------------------------------------------------------------------------ measurement
-static std::string conv_kernel_name(int mode, int cout) {
+static std::string conv_kernel_name(int mode, int cin, int cout) {
     const bool wide = cout > 64;
+    const int kch = conv_geom(mode, cin, cout).kch;
     int wm, wn, mf;
     if (mode == CONV_DN) { wm = 2; wn = 2; mf = wide ? 2 : 1; }
     else if (wide) { wm = 2; wn = 2; mf = 2; }
     else { wm = 1; wn = 4; mf = 2; }
     char buf[96];
-    snprintf(buf, sizeof buf, "gtts::conv_mfma_kernel<%d, %d, %d, %d>", mode, wm, wn, mf);
+    snprintf(buf, sizeof buf, "gtts::conv_mfma_kernel<%d, %d, %d, %d, %d>", mode, wm, wn, mf, kch);
     return buf;
 }
 
@@ -832,7 +833,7 @@ extern "C" int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, con
                 fl = 2.0 * B * o.cout * cin * taps * Ho * Wo;
                 by = 4.0 * B * (cin * Hi * Wi + o.cout * Ho * Wo);
                 if (o.epi == EPI_TAIL || o.epi == EPI_ATTN) by += 4.0 * B * o.cout * Ho * Wo;
-                s_kernel = conv_kernel_name(o.mode, o.cout);
+                s_kernel = conv_kernel_name(o.mode, o.c0 + o.c1, o.cout);
                 break;
             }
             case OP_GNFIN: s_kernel = "gtts::gn_finalize_kernel"; break;
