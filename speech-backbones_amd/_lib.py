@@ -10,7 +10,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgradtts_gfx950.so")
+LIB_PATH = os.environ.get("GTTS_LIB", os.path.join(_HERE, "libgradtts_gfx950.so"))   # GTTS_LIB: tuning variants
 
 PREC_BF16X3 = 0
 PREC_BF16 = 1

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["plan.hip", "conv_mfma.hip", "attn.hip", "misc.hip", "pack.hip", "mas.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "gradtts_abi.h")]
-LIB = os.path.join(HERE, "libgradtts_gfx950.so")
+LIB = os.path.join(HERE, os.environ.get("GTTS_LIB_NAME", "libgradtts_gfx950.so"))
 
 
 def _stale():
@@ -23,14 +23,15 @@ def build(force=False, verbose=False):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
-    bdir = os.path.join(HERE, "build")
+    bdir = os.path.join(HERE, "build", os.path.basename(LIB).replace(".so", ""))
     os.makedirs(bdir, exist_ok=True)
     procs = []
     for src in SOURCES:
         obj = os.path.join(bdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-               "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+        cmd += os.environ.get("GTTS_EXTRA_FLAGS", "").split()
+        cmd += ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

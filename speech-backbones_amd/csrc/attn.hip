@@ -39,6 +39,7 @@ __device__ __forceinline__ void pack8_split(const float (&v)[8], u32x4 &hi, u32x
     lo = *reinterpret_cast<u32x4 *>(&vl);
 }
 
+template <int NSPLIT>
 __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
     constexpr int KCH = ATTN_KCH, NKG = 2 * KCH;
     __shared__ __attribute__((aligned(16))) u32x4 s_ah[NKG * 256];
@@ -55,17 +56,14 @@ __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
 
     float raw[NKG][8];
     u32x4 wregs[KCH];
+    // unconditional loads from clamped addresses; out-of-range pixels / channels are zeroed at the split
     auto load = [&](int tile, int stage) {
-        const int n = tile * 256 + tid;
-        const bool nv = n < a.HW;
+        const int n = min(tile * 256 + tid, a.HW - 1);
 #pragma unroll
         for (int kg = 0; kg < NKG; ++kg) {
             const int cb = stage * 16 * KCH + kg * 8;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const bool ok = nv && (cb + i) < a.C;
-                raw[kg][i] = ok ? xb[(size_t)(cb + i) * a.HW + n] : 0.f;
-            }
+            for (int i = 0; i < 8; ++i) raw[kg][i] = xb[(size_t)min(cb + i, a.C - 1) * a.HW + n];
         }
         const u32x4 *g = wblk + (size_t)stage * (2 * NKG * 64);
 #pragma unroll
@@ -77,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
     f32x16 ctx;
 #pragma unroll
     for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
-    const bool lo_on = a.nsplit > 1;
+    constexpr bool lo_on = NSPLIT > 1;
 
     load(tile0, 0);
     for (int tile = tile0; tile < tile1; ++tile) {
@@ -91,9 +89,13 @@ __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
 
         for (int stage = 0; stage < a.nstage; ++stage) {
             __syncthreads();
+            const bool nv = tile * 256 + tid < a.HW;
 #pragma unroll
             for (int kg = 0; kg < NKG; ++kg) {
                 u32x4 hi, lo;
+                const int cb = stage * 16 * KCH + kg * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) raw[kg][i] = (nv && cb + i < a.C) ? raw[kg][i] : 0.f;
                 pack8_split(raw[kg], hi, lo);
                 s_ah[kg * 256 + tid] = hi;
                 s_al[kg * 256 + tid] = lo;
@@ -209,7 +211,8 @@ hipError_t launch_attn_ctx(const float *x, const unsigned char *wkv, float *part
     a.x = x; a.wkv = wkv; a.partials = partials; a.C = C; a.HW = HW;
     a.nstage = (C + 16 * ATTN_KCH - 1) / (16 * ATTN_KCH);
     a.tiles = g.tiles; a.tps = g.tps; a.nrec = g.nrec; a.nsplit = nsplit;
-    hipLaunchKernelGGL(attn_ctx_kernel, dim3(g.nslices, 4, B), dim3(256), 0, st, a);
+    if (nsplit > 1) hipLaunchKernelGGL(attn_ctx_kernel<2>, dim3(g.nslices, 4, B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(attn_ctx_kernel<1>, dim3(g.nslices, 4, B), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

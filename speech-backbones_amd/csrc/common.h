@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 
 namespace gtts {
 
@@ -100,7 +101,8 @@ static inline ConvGeom conv_geom(int mode, int cin, int cout) {
     ConvGeom g;
     bool wide = cout > 64;
     g.MT = wide ? 128 : 64;
-    g.kch = (mode == CONV_DN || cin <= 16) ? 1 : 2;
+    g.kch = 1;   // 16-channel chunks: measured faster than 32 (occupancy: 3 workgroups per CU beat fewer barriers)
+    (void)cin;
     if (mode == CONV_DN) { g.TR = 4; g.nst = 3; g.tps = 3; }
     else if (mode == CONV_UP) { g.TR = wide ? 4 : 8; g.nst = 2; g.tps = 2; }
     else if (mode == CONV_P1) { g.TR = wide ? 4 : 8; g.nst = 1; g.tps = 1; }

@@ -9,19 +9,28 @@
 // Data layout: activations stay in the reference's NCHW fp32 layout ([B,C,mel-bin,frame], frame fastest), so
 // global loads are coalesced along the mel-frame axis.  GEMM view per workgroup:
 //     D[cout (MT)][pixel (TR x 32)] = sum_{tap, cin} W[cout][cin, tap] * X[cin][pixel + tap]
-// with cin walked in chunks of 16*KCH (K of v_mfma_f32_32x32x16_bf16 is 16; KCH k-steps per chunk).  Per chunk the workgroup stages the halo
-// tile of 16 input channels into LDS *through registers*, applying the producer's epilogue on the way
-// (GroupNorm affine + Mish + mask + time bias: "apply-on-load", so normalised tensors never touch HBM) and
+// with cin walked in chunks of 16*KCH (K of v_mfma_f32_32x32x16_bf16 is 16).  Per chunk the workgroup stages the
+// halo tile of the chunk's input channels into LDS *through registers*, applying the producer's epilogue on the
+// way (GroupNorm affine + Mish + mask + time bias: "apply-on-load", so normalised tensors never touch HBM) and
 // splitting fp32 into bf16 hi/lo.  LDS image: [kgroup(2*KCH)][pixel][8 channels] x {hi, lo}: one 16-byte slot per
 // (pixel, 8-channel group) -> both the staging ds_write_b128 and the MFMA B-fragment ds_read_b128 are
 // conflict-free, and a tap is just a pixel offset.  Weights are pre-packed on the device (pack.hip) in
 // exactly the LDS image order, one contiguous block per (chunk, stage, cout tile).
 //
-// Precision: nsplit == 2 computes hi*hi + hi*lo + lo*hi with fp32 accumulation (error ~2^-17 per product,
-// i.e. fp32-grade: SURVEY.md section 0); nsplit == 1 is plain bf16.
+// Everything that selects code (mode, tiling, prologue, epilogue, precision) is a template parameter: the staging
+// loop is straight-line code (unconditional loads from clamped addresses + selects, no exec-mask branches).
+//
+// Precision: NSPLIT == 2 computes hi*hi + hi*lo + lo*hi with fp32 accumulation (error ~2^-17 per product,
+// i.e. fp32-grade: SURVEY.md section 0); NSPLIT == 1 is plain bf16.
 //
 // Wave tile: (MF x 32) output channels x (2 rows x 32 columns) pixels; a workgroup is WM x WN waves.
 #include "common.h"
+
+// minimum waves per SIMD requested from the register allocator (= workgroups per CU with 4-wave workgroups)
+#ifndef GTTS_C3_WAVES
+#define GTTS_C3_WAVES 3
+#endif
+#define GTTS_WAVES(MODE) ((MODE) == CONV_DN ? 2 : GTTS_C3_WAVES)
 
 namespace gtts {
 
@@ -42,13 +51,14 @@ struct ConvCfg {
     static_assert(WBLK16 % 256 == 0, "weight block must be a whole number of 256 x 16-byte rows");
 };
 
-static inline size_t conv_smem_bytes(int npix, int nkg, int wblk16, int cin, int pro) {
+static inline size_t conv_smem_bytes(int npix, int nkg, int wblk16, int cin, int pro, int mt) {
     size_t cpad = (size_t)((cin + 8 * nkg - 1) / (8 * nkg)) * 8 * nkg;
-    return (size_t)npix * nkg * 16 * 2 + (size_t)wblk16 * 16 + (pro == PRO_GN ? 3 * cpad * 4 : 0) + 4 * 2 * 4 * 2 * 4;
+    return (size_t)npix * nkg * 16 * 2 + (size_t)wblk16 * 16 + (pro == PRO_GN ? 3 * cpad * 4 : 0) + 4 * 2 * 4 * 2 * 4 +
+           (size_t)3 * mt * 4;
 }
 
-template <int MODE, int WM, int WN, int MF, int KCH>
-__global__ __launch_bounds__(256, (MODE == CONV_P1 && !(WM == 1 && KCH == 2)) ? 3 : 2) void conv_mfma_kernel(const ConvArgs a) {
+template <int MODE, int WM, int WN, int MF, int KCH, int PRO, int EPI, int NSPLIT>
+__global__ __launch_bounds__(256, GTTS_WAVES(MODE)) void conv_mfma_kernel(const ConvArgs a) {
     using C = ConvCfg<MODE, WM, WN, MF, KCH>;
     constexpr int MT = C::MT, TR = C::TR, TC = C::TC, NST = C::NST, TPS = C::TPS, NKG = C::NKG;
     constexpr int HC = C::HC, NPIX = C::NPIX, AITER = C::AITER, WBLK16 = C::WBLK16, WITER = C::WITER;
@@ -58,8 +68,9 @@ __global__ __launch_bounds__(256, (MODE == CONV_P1 && !(WM == 1 && KCH == 2)) ? 
     u32x4 *s_al = s_ah + NKG * NPIX;                    // [NKG][NPIX]  lo
     u32x4 *s_w = s_al + NKG * NPIX;                     // [split][tap][kg][MT]
     const int cpad = a.nchunk * 8 * NKG;
-    float *s_par = reinterpret_cast<float *>(s_w + WBLK16);   // [3][cpad]: scale, shift, time bias
-    float *s_red = s_par + (a.pro == PRO_GN ? 3 * cpad : 0);  // [4 waves][MF][4 slots][2]
+    float *s_par = reinterpret_cast<float *>(s_w + WBLK16);   // PRO_GN: [3][cpad] scale, shift, time bias
+    float *s_red = s_par + (PRO == PRO_GN ? 3 * cpad : 0);    // [4 waves][MF][4 octets][2]
+    float *s_epi = s_red + 4 * 2 * 4 * 2;                     // [3][MT]: bias, (EPI_TAIL) GN scale, shift
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kg_l = lane >> 5;
@@ -76,53 +87,63 @@ __global__ __launch_bounds__(256, (MODE == CONV_P1 && !(WM == 1 && KCH == 2)) ? 
     const int HWin = a.Hin * a.Win;
 
     // ---- per-(sample, channel) prologue parameters -> LDS (visible after the first barrier)
-    if (a.pro == PRO_GN) {
+    if (PRO == PRO_GN) {
         for (int i = tid; i < cpad; i += 256) {
-            bool ok = i < a.cin;
-            s_par[i] = ok ? a.sc[(size_t)b * a.cin + i] : 0.f;
-            s_par[cpad + i] = ok ? a.sh[(size_t)b * a.cin + i] : 0.f;
-            s_par[2 * cpad + i] = ok ? a.tb[(size_t)b * a.tb_stride + i] : 0.f;
+            const bool ok = i < a.cin;
+            const int ic = ok ? i : 0;
+            const float v0 = a.sc[(size_t)b * a.cin + ic], v1 = a.sh[(size_t)b * a.cin + ic];
+            const float v2 = a.tb[(size_t)b * a.tb_stride + ic];
+            s_par[i] = ok ? v0 : 0.f;
+            s_par[cpad + i] = ok ? v1 : 0.f;
+            s_par[2 * cpad + i] = ok ? v2 : 0.f;
         }
     }
 
-    // ---- staging items: geometry is chunk-invariant
-    int it_goff[AITER];     // offset inside a channel plane, -1 = outside the image / no item
-    int it_lds[AITER];      // destination slot in s_ah / s_al
-    int it_kg8[AITER];      // first channel of the item inside the chunk (kgroup * 8)
-    float it_m[AITER];      // mask value at the item's frame (0 outside the image)
+    // ---- per-output-channel epilogue parameters -> LDS (read after many barriers)
+    for (int i = tid; i < MT; i += 256) {
+        const int co = cot * MT + i;       // host guarantees cout % MT == 0
+        s_epi[i] = a.bias[(size_t)b * a.bias_bstride + co];
+        if (EPI == EPI_TAIL) {
+            s_epi[MT + i] = a.esc[(size_t)b * a.cout + co];
+            s_epi[2 * MT + i] = a.esh[(size_t)b * a.cout + co];
+        }
+    }
+
+    // ---- staging items: geometry is chunk-invariant.  Out-of-image items load from offset 0 (valid memory)
+    // and are zeroed by a select.
+    int it_goff[AITER];     // offset inside a channel plane (clamped to 0 when outside the image)
+    float it_m[AITER];      // mask value at the item's frame; < 0 encodes "outside the image / no item"
 #pragma unroll
     for (int it = 0; it < AITER; ++it) {
-        int idx = tid + it * 256;
-        bool has = idx < NKG * NPIX;
-        int kg = idx / NPIX;
-        int p = idx - kg * NPIX;
-        int pr = p / HC, pc = p - pr * HC;
-        int gy = iy0 + pr, gx = ix0 + pc;
-        bool in = has && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
-        it_goff[it] = in ? gy * a.Win + gx : -1;
-        int lc = pc;
-        if (MODE == CONV_DN) lc = (pc & 1) ? 33 + (pc >> 1) : (pc >> 1);   // column-parity planes
-        it_lds[it] = has ? kg * NPIX + pr * HC + lc : -1;
-        it_kg8[it] = kg * 8;
-        float m = 0.f;
-        if (in) m = (a.pro == PRO_PLAIN) ? 1.f : a.mask[(size_t)b * a.T + ((size_t)gx << a.lvl_in)];
-        it_m[it] = m;
+        const int idx = tid + it * 256;
+        const bool has = idx < NKG * NPIX;
+        const int kg = idx / NPIX;
+        const int p = idx - kg * NPIX;
+        const int pr = p / HC, pc = p - pr * HC;
+        const int gy = iy0 + pr, gx = ix0 + pc;
+        const bool in = has && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+        it_goff[it] = in ? gy * a.Win + gx : 0;
+        float m = 1.f;
+        if (PRO != PRO_PLAIN) m = a.mask[(size_t)b * a.T + ((size_t)(in ? gx : 0) << a.lvl_in)];
+        it_m[it] = in ? m : -1.f;
     }
 
     float araw[AITER][8];
     auto load_act = [&](int chunk) {
 #pragma unroll
         for (int it = 0; it < AITER; ++it) {
-            int cbase = chunk * (8 * NKG) + it_kg8[it];
-            const float *src;
-            int cloc, ctot;
-            if (cbase < a.c0) { src = a.src0; cloc = cbase; ctot = a.c0; }
-            else { src = a.src1; cloc = cbase - a.c0; ctot = a.c1; }
-            const float *pl = src + ((size_t)b * ctot + cloc) * HWin + (it_goff[it] < 0 ? 0 : it_goff[it]);
+            const int idx = tid + it * 256;
+            const int kg = min(idx / NPIX, NKG - 1);
+            const int cbase = chunk * (8 * NKG) + kg * 8;
+            const int nval = min(max(a.cin - cbase, 0), 8);        // valid channels of this 8-group
+            const int cb0 = nval > 0 ? cbase : 0;
+            const float *pl = (cb0 < a.c0) ? a.src0 + ((size_t)b * a.c0 + cb0) * HWin
+                                           : a.src1 + ((size_t)b * a.c1 + (cb0 - a.c0)) * HWin;
+            pl += it_goff[it];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                bool ok = it_goff[it] >= 0 && (cbase + i) < a.cin;
-                araw[it][i] = ok ? pl[(size_t)i * HWin] : 0.f;
+                const int ii = min(i, max(nval, 1) - 1);            // clamp: always a valid address
+                araw[it][i] = pl[(size_t)ii * HWin];                 // zeroing of i >= nval happens at use
             }
         }
     };
@@ -148,33 +169,56 @@ __global__ __launch_bounds__(256, (MODE == CONV_P1 && !(WM == 1 && KCH == 2)) ? 
     load_act(0);
 
     const int m0 = wm * MF * 32;
-    const bool lo_on = a.nsplit > 1;
 
     for (int chunk = 0; chunk < a.nchunk; ++chunk) {
         __syncthreads();   // previous chunk's MFMAs are done with s_a* / s_w (and s_par is written)
-        // ---- transform + split + stage the activation tile of this chunk
+        // ---- transform + split + stage the activation tile of this chunk (straight-line code)
 #pragma unroll
         for (int it = 0; it < AITER; ++it) {
-            if (it_lds[it] >= 0) {
-                const float m = it_m[it];
-                const int cb = chunk * (8 * NKG) + it_kg8[it];
-                bf16x8 vh, vl;
+            const int idx = tid + it * 256;
+            const int kg = min(idx / NPIX, NKG - 1);
+            const int p = idx - (idx / NPIX) * NPIX;
+            const int pr = p / HC, pc = p - pr * HC;
+            int lc = pc;
+            if (MODE == CONV_DN) lc = (pc & 1) ? 33 + (pc >> 1) : (pc >> 1);   // column-parity planes
+            const bool has = idx < NKG * NPIX;
+            const float mraw = it_m[it];
+            const bool inb = mraw >= 0.f;
+            const float m = inb ? mraw : 0.f;
+            const int cb = chunk * (8 * NKG) + kg * 8;
+            const int nval = min(max(a.cin - cb, 0), 8);
+            float sc[8], sh[8], tb[8];
+            if (PRO == PRO_GN) {
+                const float4 *q = reinterpret_cast<const float4 *>(s_par + cb);
+                const float4 *q1 = reinterpret_cast<const float4 *>(s_par + cpad + cb);
+                const float4 *q2 = reinterpret_cast<const float4 *>(s_par + 2 * cpad + cb);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    float v = araw[it][i];
-                    if (a.pro == PRO_MASK) {
-                        v *= m;
-                    } else if (a.pro == PRO_GN) {
-                        float y = v * s_par[cb + i] + s_par[cpad + cb + i];
-                        v = (mish_f(y) * m + s_par[2 * cpad + cb + i]) * m;
-                    }
-                    __bf16 h, l;
-                    split_bf16(v, h, l);
-                    vh[i] = h;
-                    vl[i] = l;
+                for (int h = 0; h < 2; ++h) {
+                    const float4 u = q[h], u1 = q1[h], u2 = q2[h];
+                    sc[4 * h + 0] = u.x; sc[4 * h + 1] = u.y; sc[4 * h + 2] = u.z; sc[4 * h + 3] = u.w;
+                    sh[4 * h + 0] = u1.x; sh[4 * h + 1] = u1.y; sh[4 * h + 2] = u1.z; sh[4 * h + 3] = u1.w;
+                    tb[4 * h + 0] = u2.x; tb[4 * h + 1] = u2.y; tb[4 * h + 2] = u2.z; tb[4 * h + 3] = u2.w;
                 }
-                s_ah[it_lds[it]] = *reinterpret_cast<u32x4 *>(&vh);
-                s_al[it_lds[it]] = *reinterpret_cast<u32x4 *>(&vl);
+            }
+            bf16x8 vh, vl;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v = (inb && i < nval) ? araw[it][i] : 0.f;
+                if (PRO == PRO_MASK) {
+                    v *= m;
+                } else if (PRO == PRO_GN) {
+                    const float y = v * sc[i] + sh[i];
+                    v = (mish_f(y) * m + tb[i]) * m;
+                }
+                __bf16 h, l;
+                split_bf16(v, h, l);
+                vh[i] = h;
+                vl[i] = l;
+            }
+            if (has) {
+                const int slot = kg * NPIX + pr * HC + lc;
+                s_ah[slot] = *reinterpret_cast<u32x4 *>(&vh);
+                s_al[slot] = *reinterpret_cast<u32x4 *>(&vl);
             }
         }
 #pragma unroll
@@ -210,19 +254,19 @@ __global__ __launch_bounds__(256, (MODE == CONV_P1 && !(WM == 1 && KCH == 2)) ? 
                     for (int mi = 0; mi < MF; ++mi) {
                         int wi = (j * NKG + kc * 2 + kg_l) * MT + m0 + mi * 32 + l31;
                         wh[mi] = *reinterpret_cast<const bf16x8 *>(&s_w[wi]);
-                        wl[mi] = *reinterpret_cast<const bf16x8 *>(&s_w[wi + TPS * NKG * MT]);
+                        if (NSPLIT > 1) wl[mi] = *reinterpret_cast<const bf16x8 *>(&s_w[wi + TPS * NKG * MT]);
                     }
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni) {
                         int xi = (kc * 2 + kg_l) * NPIX + po[ni] + l31;
                         xh[ni] = *reinterpret_cast<const bf16x8 *>(&s_ah[xi]);
-                        xl[ni] = *reinterpret_cast<const bf16x8 *>(&s_al[xi]);
+                        if (NSPLIT > 1) xl[ni] = *reinterpret_cast<const bf16x8 *>(&s_al[xi]);
                     }
 #pragma unroll
                     for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
                         for (int ni = 0; ni < 2; ++ni) {
-                            if (lo_on) {
+                            if (NSPLIT > 1) {
                                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[mi], xh[ni], acc[mi][ni], 0, 0, 0);
                                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[mi], xl[ni], acc[mi][ni], 0, 0, 0);
                             }
@@ -235,8 +279,6 @@ __global__ __launch_bounds__(256, (MODE == CONV_P1 && !(WM == 1 && KCH == 2)) ? 
 
     // ---------------------------------------------------------------- epilogue
     const int HWout = a.Hout * a.Wout;
-    const int gs = a.cout / a.groups;                   // channels per GroupNorm group (EPI_STATS)
-    const float *bias = a.bias + (size_t)b * a.bias_bstride;
     float st1[MF][4], st2[MF][4];
 #pragma unroll
     for (int mi = 0; mi < MF; ++mi)
@@ -249,28 +291,34 @@ __global__ __launch_bounds__(256, (MODE == CONV_P1 && !(WM == 1 && KCH == 2)) ? 
         int oy = y0 + r, ox = x0 + l31;
         if (MODE == CONV_UP) { oy = 2 * oy + ph_y; ox = 2 * ox + ph_x; }
         const bool pix_ok = oy < a.Hout && ox < a.Wout;
-        float m_out = 0.f;
-        if (a.epi == EPI_TAIL && pix_ok) m_out = a.mask[(size_t)b * a.T + ((size_t)ox << a.lvl_out)];
+        if (pix_ok) {      // one exec-mask region per row; straight-line code inside
+            float m_out = 0.f;
+            if (EPI == EPI_TAIL) m_out = a.mask[(size_t)b * a.T + ((size_t)ox << a.lvl_out)];
+            const size_t obase = ((size_t)b * a.cout + cot * MT) * HWout + (size_t)oy * a.Wout + ox;
 #pragma unroll
-        for (int mi = 0; mi < MF; ++mi) {
+            for (int mi = 0; mi < MF; ++mi) {
+                float ex[16];
+                if (EPI == EPI_TAIL || EPI == EPI_ATTN) {
+                    const float *ep = (EPI == EPI_TAIL ? a.eh : a.eres) + obase;
 #pragma unroll
-            for (int rg = 0; rg < 16; ++rg) {
-                const int co = cot * MT + m0 + mi * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kg_l;
-                const bool ok = pix_ok && co < a.cout;
-                float v = acc[mi][ni][rg];
-                if (ok) {
-                    v += bias[co];
-                    const size_t o = ((size_t)b * a.cout + co) * HWout + (size_t)oy * a.Wout + ox;
-                    if (a.epi == EPI_TAIL) {
-                        float y = a.eh[o] * a.esc[(size_t)b * a.cout + co] + a.esh[(size_t)b * a.cout + co];
-                        v += mish_f(y) * m_out;
-                    } else if (a.epi == EPI_ATTN) {
-                        v += a.eres[o];
+                    for (int rg = 0; rg < 16; ++rg) {
+                        const int col = m0 + mi * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kg_l;
+                        ex[rg] = ep[(size_t)col * HWout];
                     }
-                    a.out[o] = v;
-                    if (a.epi == EPI_STATS) {
-                        // slot rg>>2 = the 8-channel octet of this 32-channel fragment (static index:
-                        // runtime-indexed register arrays would go to scratch); octets -> groups below
+                }
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int col = m0 + mi * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kg_l;   // channel inside the tile
+                    float v = acc[mi][ni][rg] + s_epi[col];
+                    if (EPI == EPI_TAIL) {
+                        const float y = ex[rg] * s_epi[MT + col] + s_epi[2 * MT + col];
+                        v += mish_f(y) * m_out;
+                    } else if (EPI == EPI_ATTN) {
+                        v += ex[rg];
+                    }
+                    a.out[obase + (size_t)col * HWout] = v;
+                    if (EPI == EPI_STATS) {
+                        // octet rg>>2 of this 32-channel fragment (static index); octets -> groups below
                         st1[mi][rg >> 2] += v;
                         st2[mi][rg >> 2] += v * v;
                     }
@@ -279,9 +327,10 @@ __global__ __launch_bounds__(256, (MODE == CONV_P1 && !(WM == 1 && KCH == 2)) ? 
         }
     }
 
-    if (a.epi == EPI_STATS) {
+    if (EPI == EPI_STATS) {
         // wave reduce -> LDS -> fixed-order combine: one partial per (workgroup, group), deterministic
-        __syncthreads();   // s_red aliases nothing live, but keep ordering simple
+        const int gs = a.cout / a.groups;                   // channels per GroupNorm group
+        __syncthreads();
 #pragma unroll
         for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
@@ -320,7 +369,7 @@ __global__ __launch_bounds__(256, (MODE == CONV_P1 && !(WM == 1 && KCH == 2)) ? 
     }
 }
 
-template <int MODE, int WM, int WN, int MF, int KCH>
+template <int MODE, int WM, int WN, int MF, int KCH, int PRO, int EPI, int NSPLIT>
 static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
     using C = ConvCfg<MODE, WM, WN, MF, KCH>;
     ConvArgs a = a_in;
@@ -331,15 +380,17 @@ static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
     a.tiles_y = (th + C::TR - 1) / C::TR;
     const int ncot = (a.cout + C::MT - 1) / C::MT;
     dim3 grid(a.tiles_x * a.tiles_y, ncot * (MODE == CONV_UP ? 4 : 1), a.B);
-    size_t smem = conv_smem_bytes(C::NPIX, C::NKG, C::WBLK16, a.cin, a.pro);
+    if (a.cout % C::MT != 0) return hipErrorInvalidValue;   // epilogue assumes whole output-channel tiles
+    size_t smem = conv_smem_bytes(C::NPIX, C::NKG, C::WBLK16, a.cin, PRO, C::MT);
     static size_t attr_set = 0;
     if (smem > attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<MODE, WM, WN, MF, KCH>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&conv_mfma_kernel<MODE, WM, WN, MF, KCH, PRO, EPI, NSPLIT>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr_set = smem;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, MF, KCH>), grid, dim3(256), smem, st, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, MF, KCH, PRO, EPI, NSPLIT>), grid, dim3(256), smem, st, a);
     return hipGetLastError();
 }
 
@@ -349,22 +400,43 @@ int conv_nparts(int mode, int cout, int Hout, int Wout) {
     return ((Wout + 31) / 32) * ((Hout + g.TR - 1) / g.TR);
 }
 
-// template instances; must agree with conv_geom() in common.h
+// (mode, tiling) x (prologue, epilogue) x precision -> template instance; must agree with conv_geom() in common.h.
+// Only the combinations the op program uses are instantiated:
+//   C3: (MASK | GN, STATS)   DN, UP: (MASK, PLAIN)   P1: (MASK, TAIL) | (PLAIN, ATTN)
+template <int MODE, int WM, int WN, int MF, int PRO, int EPI>
+static hipError_t launch_prec(const ConvArgs &a, hipStream_t st) {
+    return a.nsplit > 1 ? launch_cfg<MODE, WM, WN, MF, 1, PRO, EPI, 2>(a, st)
+                        : launch_cfg<MODE, WM, WN, MF, 1, PRO, EPI, 1>(a, st);
+}
+
 hipError_t launch_conv(int mode, const ConvArgs &a, hipStream_t st) {
     const bool wide = a.cout > 64;
-    const bool k1 = a.cin <= 16;
     switch (mode) {
         case CONV_C3:
-            if (wide) return k1 ? launch_cfg<CONV_C3, 2, 2, 2, 1>(a, st) : launch_cfg<CONV_C3, 2, 2, 2, 2>(a, st);
-            return k1 ? launch_cfg<CONV_C3, 1, 4, 2, 1>(a, st) : launch_cfg<CONV_C3, 1, 4, 2, 2>(a, st);
+            if (a.epi != EPI_STATS) break;
+            if (a.pro == PRO_MASK)
+                return wide ? launch_prec<CONV_C3, 2, 2, 2, PRO_MASK, EPI_STATS>(a, st)
+                            : launch_prec<CONV_C3, 1, 4, 2, PRO_MASK, EPI_STATS>(a, st);
+            if (a.pro == PRO_GN)
+                return wide ? launch_prec<CONV_C3, 2, 2, 2, PRO_GN, EPI_STATS>(a, st)
+                            : launch_prec<CONV_C3, 1, 4, 2, PRO_GN, EPI_STATS>(a, st);
+            break;
         case CONV_DN:
-            return wide ? launch_cfg<CONV_DN, 2, 2, 2, 1>(a, st) : launch_cfg<CONV_DN, 2, 2, 1, 1>(a, st);
+            if (a.pro != PRO_MASK || a.epi != EPI_PLAIN) break;
+            return wide ? launch_prec<CONV_DN, 2, 2, 2, PRO_MASK, EPI_PLAIN>(a, st)
+                        : launch_prec<CONV_DN, 2, 2, 1, PRO_MASK, EPI_PLAIN>(a, st);
         case CONV_UP:
-            if (wide) return k1 ? launch_cfg<CONV_UP, 2, 2, 2, 1>(a, st) : launch_cfg<CONV_UP, 2, 2, 2, 2>(a, st);
-            return k1 ? launch_cfg<CONV_UP, 1, 4, 2, 1>(a, st) : launch_cfg<CONV_UP, 1, 4, 2, 2>(a, st);
+            if (a.pro != PRO_MASK || a.epi != EPI_PLAIN) break;
+            return wide ? launch_prec<CONV_UP, 2, 2, 2, PRO_MASK, EPI_PLAIN>(a, st)
+                        : launch_prec<CONV_UP, 1, 4, 2, PRO_MASK, EPI_PLAIN>(a, st);
         case CONV_P1:
-            if (wide) return k1 ? launch_cfg<CONV_P1, 2, 2, 2, 1>(a, st) : launch_cfg<CONV_P1, 2, 2, 2, 2>(a, st);
-            return k1 ? launch_cfg<CONV_P1, 1, 4, 2, 1>(a, st) : launch_cfg<CONV_P1, 1, 4, 2, 2>(a, st);
+            if (a.pro == PRO_MASK && a.epi == EPI_TAIL)
+                return wide ? launch_prec<CONV_P1, 2, 2, 2, PRO_MASK, EPI_TAIL>(a, st)
+                            : launch_prec<CONV_P1, 1, 4, 2, PRO_MASK, EPI_TAIL>(a, st);
+            if (a.pro == PRO_PLAIN && a.epi == EPI_ATTN)
+                return wide ? launch_prec<CONV_P1, 2, 2, 2, PRO_PLAIN, EPI_ATTN>(a, st)
+                            : launch_prec<CONV_P1, 1, 4, 2, PRO_PLAIN, EPI_ATTN>(a, st);
+            break;
     }
     return hipErrorInvalidValue;
 }

@@ -789,7 +789,7 @@ extern "C" int gtts_mas_maximum_path(const float *value, const float *mask, cons
 
 
 // ------------------------------------------------------------------------------------------------ measurement
-static std::string conv_kernel_name(int mode, int cin, int cout) {
+static std::string conv_kernel_name(int mode, int cin, int cout, int pro, int epi, int nsplit) {
     const bool wide = cout > 64;
     const int kch = conv_geom(mode, cin, cout).kch;
     int wm, wn, mf;
@@ -797,7 +797,7 @@ static std::string conv_kernel_name(int mode, int cin, int cout) {
     else if (wide) { wm = 2; wn = 2; mf = 2; }
     else { wm = 1; wn = 4; mf = 2; }
     char buf[96];
-    snprintf(buf, sizeof buf, "gtts::conv_mfma_kernel<%d, %d, %d, %d, %d>", mode, wm, wn, mf, kch);
+    snprintf(buf, sizeof buf, "gtts::conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", mode, wm, wn, mf, kch, pro, epi, nsplit);
     return buf;
 }
 
@@ -833,12 +833,12 @@ extern "C" int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, con
                 fl = 2.0 * B * o.cout * cin * taps * Ho * Wo;
                 by = 4.0 * B * (cin * Hi * Wi + o.cout * Ho * Wo);
                 if (o.epi == EPI_TAIL || o.epi == EPI_ATTN) by += 4.0 * B * o.cout * Ho * Wo;
-                s_kernel = conv_kernel_name(o.mode, o.c0 + o.c1, o.cout);
+                s_kernel = conv_kernel_name(o.mode, o.c0 + o.c1, o.cout, o.pro, o.epi, plan->cfg.precision == GTTS_PREC_BF16 ? 1 : 2);
                 break;
             }
             case OP_GNFIN: s_kernel = "gtts::gn_finalize_kernel"; break;
             case OP_TAILID: s_kernel = "gtts::tail_identity_kernel"; by = 4.0 * B * o.C * Hi * Wi * 3; break;
-            case OP_ACTX: s_kernel = "gtts::attn_ctx_kernel"; fl = 2.0 * B * Hi * Wi * (256.0 * o.C + 128.0 * 32);
+            case OP_ACTX: s_kernel = plan->cfg.precision == GTTS_PREC_BF16 ? "gtts::attn_ctx_kernel<1>" : "gtts::attn_ctx_kernel<2>"; fl = 2.0 * B * Hi * Wi * (256.0 * o.C + 128.0 * 32);
                 by = 4.0 * B * o.C * Hi * Wi; break;
             case OP_AMERGE: s_kernel = "gtts::attn_merge_kernel"; break;
             case OP_AFOLD: s_kernel = "gtts::attn_fold_kernel"; fl = 2.0 * B * (o.C * 128.0 * 32 + (double)o.C * o.C * 128); break;
