@@ -103,6 +103,9 @@ struct gtts_plan {
     struct ProfRec { int op; hipEvent_t a, b; };
     std::vector<ProfRec> prof;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
+    // sub-streams for the sampler's two-way batch split (created on first use)
+    hipStream_t sub[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     // workspace layout cache
     int cache_B = -1, cache_T = -1;
     std::vector<size_t> offsets;
@@ -405,7 +408,27 @@ extern "C" int gtts_plan_create(const gtts_unet_cfg *cfg, gtts_plan **out) {
     return GTTS_OK;
 }
 
-extern "C" void gtts_plan_destroy(gtts_plan *plan) { delete plan; }
+extern "C" void gtts_plan_destroy(gtts_plan *plan) {
+    if (!plan) return;
+    for (int h = 0; h < 2; ++h) {
+        if (plan->sub[h]) (void)hipStreamDestroy(plan->sub[h]);
+        if (plan->ev_join[h]) (void)hipEventDestroy(plan->ev_join[h]);
+    }
+    if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
+    for (auto &e : plan->prof_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto &r : plan->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    delete plan;
+}
+
+// GTTS_STREAMS=1 disables the sampler's two-way batch split (default 2)
+static int sampler_streams() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GTTS_STREAMS");
+        v = (e && e[0] == '1') ? 1 : 2;
+    }
+    return v;
+}
 
 // registration order: spk_mlp, mlp, downs, ups, mid_block1, mid_attn, mid_block2, final_block, final_conv
 static int reg_rank(const std::string &n) {
@@ -534,7 +557,13 @@ extern "C" size_t gtts_workspace_bytes(const gtts_plan *plan, int B, int T) {
     gtts_plan *p = const_cast<gtts_plan *>(plan);
     // sized for the sampler's worst case: one tb row per step is tiny, allow up to 4096 rows
     layout_workspace(p, B, T, std::max(B, 4096));
-    return p->ws_bytes;
+    size_t whole = p->ws_bytes;
+    if (B >= 2 && sampler_streams() > 1) {       // the sampler runs two half batches side by side, each in its own half
+        const int Bh = (B + 1) / 2;
+        layout_workspace(p, Bh, T, std::max(Bh, 4096));
+        whole = std::max(whole, 2 * align_up(p->ws_bytes, 256));
+    }
+    return whole;
 }
 
 extern "C" int gtts_plan_num_tensors(const gtts_plan *plan) { return plan ? (int)plan->tensors.size() : 0; }
@@ -734,41 +763,85 @@ extern "C" int gtts_reverse_diffusion(const gtts_plan *plan, const void *packed,
     gtts_plan *p = const_cast<gtts_plan *>(plan);
     const bool multi = p->cfg.n_spks > 1;
     if (multi && !spk) return fail(GTTS_E_NULL, "multi-speaker plan needs spk");
-    rc = prepare(p, B, T, n_timesteps, workspace_bytes);
-    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const unsigned char *blob = (const unsigned char *)packed;
-    RunCtx c{p, blob, (unsigned char *)workspace, mask, B, T, nullptr, 0, st};
-    const int F = p->cfg.n_feats, N = n_timesteps;
-    float *s = nullptr;
-    if (multi) {
-        s = tptr(c, p->t_s);
-        { ProfScope ps_(p, st, (int)p->ops.size() + XOP_SPK); HIPCHK(launch_spk_mlp(spk, (const float *)(blob + p->spk_w0), (const float *)(blob + p->spk_b0),
-                              (const float *)(blob + p->spk_w2), (const float *)(blob + p->spk_b2), s, B, p->cfg.spk_emb_dim, F, st)); }
+    const int F = p->cfg.n_feats, N = n_timesteps, E = p->cfg.spk_emb_dim;
+
+    // Utterances are independent, so the batch is split in two halves that run the whole N-step loop side by side
+    // on two streams: the tail of one half's kernel overlaps the other half's next kernel, and HBM-bound kernels
+    // overlap MFMA-bound ones.  Results are bit-identical to the unsplit run (no operation mixes batch entries).
+    const int nhalf = (B >= 2 && sampler_streams() > 1) ? 2 : 1;
+    const int Bh0 = nhalf == 2 ? (B + 1) / 2 : B;
+    layout_workspace(p, Bh0, T, std::max(Bh0, 4096));
+    const size_t ws_half = align_up(p->ws_bytes, 256);
+    if (workspace_bytes < ws_half * nhalf)
+        return fail(GTTS_E_WORKSPACE, "workspace too small: need %zu bytes, got %zu", ws_half * nhalf, workspace_bytes);
+    if (nhalf == 2 && !p->sub[0]) {
+        for (int h = 0; h < 2; ++h) {
+            HIPCHK(hipStreamCreateWithFlags(&p->sub[h], hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&p->ev_join[h], hipEventDisableTiming));
+        }
+        HIPCHK(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
     }
+
+    RunCtx c0{p, blob, (unsigned char *)workspace, mask, B, T, nullptr, 0, st};
     // time embeddings of all N steps in one launch: t is batch-uniform inside the sampler (diffusion.py:259).
-    // The step times live in the 4096 floats behind the tb rows.
-    float *tb = tptr(c, p->t_tb);
-    float *tvals = tb + (size_t)std::max(B, 4096) * p->tmlp.tb_stride;
+    // The step times live in the 4096 floats behind the tb rows.  Both halves read these rows.
+    float *tb = tptr(c0, p->t_tb);
+    float *tvals = tb + (size_t)std::max(Bh0, 4096) * p->tmlp.tb_stride;
     hipLaunchKernelGGL(sampler_times_kernel, dim3((N + 255) / 256), dim3(256), 0, st, tvals, N);
     HIPCHK(hipGetLastError());
     { ProfScope ps_(p, st, (int)p->ops.size() + XOP_TIME); HIPCHK(launch_time_mlp(tvals, (const float *)(blob + p->freq_off), p->cfg.pe_scale, blob, p->tmlp, tb, N, st)); }
     { ProfScope ps_(p, st, (int)p->ops.size() + XOP_MULMASK); HIPCHK(launch_mul_mask(z, mask, out, B, F, T, st)); }           // xt = z * mask        (diffusion.py:257)
+
+    struct Half { RunCtx c; int b0; float *s; };
+    Half hv[2];
+    for (int h = 0; h < nhalf; ++h) {
+        const int b0 = h == 0 ? 0 : Bh0;
+        const int bn = h == 0 ? Bh0 : B - Bh0;
+        hipStream_t hs = nhalf == 2 ? p->sub[h] : st;
+        hv[h].c = RunCtx{p, blob, (unsigned char *)workspace + (size_t)h * ws_half, mask + (size_t)b0 * T, bn, T, nullptr, 0, hs};
+        hv[h].b0 = b0;
+        hv[h].s = nullptr;
+    }
+    if (nhalf == 2) {
+        HIPCHK(hipEventRecord(p->ev_fork, st));
+        for (int h = 0; h < 2; ++h) HIPCHK(hipStreamWaitEvent(p->sub[h], p->ev_fork, 0));
+    }
+    if (multi) {
+        for (int h = 0; h < nhalf; ++h) {
+            Half &H = hv[h];
+            H.s = tptr(H.c, p->t_s);
+            ProfScope ps_(p, H.c.st, (int)p->ops.size() + XOP_SPK);
+            HIPCHK(launch_spk_mlp(spk + (size_t)H.b0 * E, (const float *)(blob + p->spk_w0), (const float *)(blob + p->spk_b0),
+                                  (const float *)(blob + p->spk_w2), (const float *)(blob + p->spk_b2), H.s, H.c.B, E, F, H.c.st));
+        }
+    }
     const double hd = 1.0 / (double)N;
     const float h = (float)hd;
     const float bmin = p->cfg.beta_min, bdiff = (float)((double)p->cfg.beta_max - (double)p->cfg.beta_min);
     for (int i = 0; i < N; ++i) {
         const float t = (float)(1.0 - ((double)i + 0.5) * hd);
         const float beta = bmin + bdiff * t;                      // get_noise, fp32 like the reference tensor math
-        c.tb_row = tb + (size_t)i * p->tmlp.tb_stride;
-        c.tb_bstride = 0;
-        { ProfScope ps_(p, st, (int)p->ops.size() + XOP_PREP); HIPCHK(launch_prep_input(mu, out, s, tptr(c, p->t_x0), B, F, T, p->cin0, st)); }
-        rc = run_ops(c);
-        if (rc) return rc;
-        const float *nz = noise ? noise + (size_t)i * B * F * T : nullptr;
-        { ProfScope ps_(p, st, (int)p->ops.size() + XOP_FINAL); HIPCHK(launch_final_euler(tptr(c, p->t_final_raw), tptr(c, p->t_final_sc), tptr(c, p->t_final_sh),
-                                  (const float *)(blob + p->fw_off), (const float *)(blob + p->fb_off), mask, B, p->cfg.dim, F, T,
-                                  nullptr, out, mu, nz, beta, h, st)); }
+        for (int hh = 0; hh < nhalf; ++hh) {
+            Half &H = hv[hh];
+            const size_t off = (size_t)H.b0 * F * T;
+            H.c.tb_row = tb + (size_t)i * p->tmlp.tb_stride;
+            H.c.tb_bstride = 0;
+            { ProfScope ps_(p, H.c.st, (int)p->ops.size() + XOP_PREP); HIPCHK(launch_prep_input(mu + off, out + off, H.s, tptr(H.c, p->t_x0), H.c.B, F, T, p->cin0, H.c.st)); }
+            rc = run_ops(H.c);
+            if (rc) return rc;
+            const float *nz = noise ? noise + (size_t)i * B * F * T + off : nullptr;
+            { ProfScope ps_(p, H.c.st, (int)p->ops.size() + XOP_FINAL); HIPCHK(launch_final_euler(tptr(H.c, p->t_final_raw), tptr(H.c, p->t_final_sc), tptr(H.c, p->t_final_sh),
+                                      (const float *)(blob + p->fw_off), (const float *)(blob + p->fb_off), H.c.mask, H.c.B, p->cfg.dim, F, T,
+                                      nullptr, out + off, mu + off, nz, beta, h, H.c.st)); }
+        }
+    }
+    if (nhalf == 2) {
+        for (int hh = 0; hh < 2; ++hh) {
+            HIPCHK(hipEventRecord(p->ev_join[hh], p->sub[hh]));
+            HIPCHK(hipStreamWaitEvent(st, p->ev_join[hh], 0));
+        }
     }
     return GTTS_OK;
 }
