@@ -12,6 +12,8 @@ What each file pins (reference symbol -> arrays):
   rd_sde.npz     Diffusion.reverse_diffusion stoc=True  N=3, per-step randn injected
   mas.npz        monotonic_align.maximum_path (compiled core.pyx) on ragged random values
   utils.npz      sequence_mask / fix_len_compatibility / generate_path   model/utils.py:6-39
+  vc_dim64.npz   DiffVC GradLogPEstimator.forward + Diffusion.forward ('pf','em','ml', N=3, injected noise)
+                 DiffVC/model/diffusion.py:61-106,164-205 with dim_unet=64, use_ref_t=True (RefBlock path)
 """
 import os
 import sys
@@ -109,6 +111,39 @@ def main():
     gp = U.generate_path(dur, pm)
     np.savez_compressed(os.path.join(OUT, "utils.npz"), lens=lens.numpy(), seqmask=sm.numpy(), fixlen=fl,
                         dur=dur.numpy(), pmask=pm.numpy(), path=gp.numpy())
+    # ---- DiffVC decoder (DiffVC/model/diffusion.py:17-205), dim_unet=64 keeps the fixture small
+    from oracle import diffvc_oracle as V
+    vc = ref_loader.load_diffvc()
+    sdv = V.make_state(dim_base=64, dim_cond=128, use_ref_t=True, seed=0)
+    dvc = vc.diffusion.Diffusion(80, 64, 128, True, 0.05, 20.0)
+    dvc.estimator.load_state_dict(sdv, strict=True)
+    iv = V.make_inputs(2, 32, 24, seed=7)
+    tv = torch.tensor([0.7, 0.3])
+    xt_ref = torch.stack([V.compute_diffused_mean(iv["ref"], iv["ref_mask"], iv["mean_ref"], 0.7)], 1)
+    with torch.no_grad():
+        estv = dvc.estimator(iv["z"], iv["mask"], iv["mean"], xt_ref, iv["ref_mask"], iv["c"], tv)
+    g = torch.Generator().manual_seed(3)
+    noise_v = torch.randn(3, 2, 80, 32, generator=g)
+    outs = {}
+    real_rl = torch.randn_like
+    for mode in ("pf", "em", "ml"):
+        calls = {"i": 0}
+
+        def fake_rl(x, **k):
+            i = calls["i"]
+            calls["i"] += 1
+            return noise_v[i].clone()
+
+        torch.randn_like = fake_rl
+        try:
+            with torch.no_grad():
+                outs[mode] = dvc(iv["z"], iv["mask"], iv["mean"], iv["ref"], iv["ref_mask"], iv["mean_ref"], iv["c"], 3,
+                                 mode).numpy()
+        finally:
+            torch.randn_like = real_rl
+    np.savez_compressed(os.path.join(OUT, "vc_dim64.npz"), seed=0, wsum=checksum(sdv), t=tv.numpy(), xt_ref=xt_ref.numpy(),
+                        noise=noise_v.numpy(), est=estv.numpy(), out_pf=outs["pf"], out_em=outs["em"], out_ml=outs["ml"],
+                        **np_(iv))
     print("golden vectors written to", OUT)
 
 

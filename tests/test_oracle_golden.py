@@ -86,3 +86,18 @@ def test_utils_match_reference_outputs():
     assert np.array_equal(O.sequence_mask(_t(g["lens"]), 9).numpy(), g["seqmask"])
     assert [O.fix_len_compatibility(n) for n in range(0, 20)] == list(g["fixlen"])
     assert np.array_equal(O.generate_path(_t(g["dur"]), _t(g["pmask"])).numpy(), g["path"])
+
+
+def test_diffvc_oracle_matches_reference_outputs():
+    from oracle import diffvc_oracle as V
+    g = golden("vc_dim64.npz")
+    sd = V.make_state(dim_base=64, dim_cond=128, use_ref_t=True, seed=int(g["seed"]))
+    assert abs(_wsum(sd) - float(g["wsum"])) <= 1e-6 * float(g["wsum"])
+    est = V.estimator_forward(sd, _t(g["z"]), _t(g["mask"]), _t(g["mean"]), _t(g["xt_ref"]), _t(g["ref_mask"]), _t(g["c"]),
+                              _t(g["t"]))
+    assert torch.allclose(est, _t(g["est"]), rtol=0, atol=2e-5)
+    for mode in ("pf", "em", "ml"):
+        out = V.reverse_diffusion(sd, _t(g["z"]), _t(g["mask"]), _t(g["mean"]), _t(g["ref"]), _t(g["ref_mask"]),
+                                  _t(g["mean_ref"]), _t(g["c"]), 3, mode, noise=_t(g["noise"]))
+        ref = _t(g["out_" + mode])
+        assert (out - ref).abs().max() <= 1e-5 * ref.abs().max()
