@@ -60,6 +60,13 @@ typedef struct gtts_unet_cfg {
     float beta_max;      /* 20.0                                             */
     int precision;       /* GTTS_PREC_*                                      */
     int keep_intermediates; /* 1: every op output gets its own workspace slot (tests / debugging)       */
+    /* ---- DiffVC decoder (DiffVC/model/diffusion.py:17-59): arch = 1, dim = dim_base (256), pe_scale 1000 */
+    int arch;            /* 0: Grad-TTS GradLogPEstimator2d, 1: DiffVC GradLogPEstimator                 */
+    int dim_cond;        /* 128: condition channels appended to [mean, x] (130 input channels)          */
+    int use_ref_t;       /* 1: RefBlock on the diffused reference mel feeds the condition                */
+    int c_dim;           /* 256: speaker-embedding width                                                 */
+    double vc_beta_min;  /* DiffVC schedule scalars are Python doubles in the reference (diffusion.py:120-149) */
+    double vc_beta_max;
 } gtts_unet_cfg;
 
 typedef struct gtts_plan gtts_plan;   /* host-side metadata only */
@@ -102,6 +109,22 @@ int gtts_euler_step(float *xt, const float *mu, const float *est, const float *m
 int gtts_reverse_diffusion(const gtts_plan *plan, const void *packed, const float *z, const float *mask,
                            const float *mu, const float *spk, const float *noise, float *out, void *workspace,
                            size_t workspace_bytes, int B, int T, int n_timesteps, gtts_stream_t stream);
+
+/* ---- DiffVC: GradLogPEstimator.forward(x, x_mask, mean, ref, ref_mask, c, t)  DiffVC/model/diffusion.py:61-106 -- */
+/* x, mean, out [B,F,T]; x_mask [B,T]; xt_ref [B,1,F,T_ref] (the diffused reference, diffusion.py:173-176);
+ * ref_mask [B,T_ref]; c [B,c_dim]; t [B].  T % 4 == 0; T_ref is free. */
+size_t gtts_vc_workspace_bytes(const gtts_plan *plan, int B, int T, int T_ref);
+int gtts_vc_estimator_forward(const gtts_plan *plan, const void *packed, const float *x, const float *x_mask,
+                              const float *mean, const float *xt_ref, const float *ref_mask, const float *c, const float *t,
+                              float *out, void *workspace, size_t workspace_bytes, int B, int T, int T_ref,
+                              gtts_stream_t stream);
+/* ---- DiffVC: Diffusion.reverse_diffusion / forward  DiffVC/model/diffusion.py:164-205 ------------------------ */
+/* mode 0 'pf', 1 'em', 2 'ml'; noise [N,B,F,T] pre-drawn N(0,1) (required for em / ml, ignored for pf);
+ * ref, mean_ref [B,F,T_ref].  The schedule scalars (beta, gamma, mu, nu, sigma, kappa, omega) are host doubles. */
+int gtts_vc_reverse_diffusion(const gtts_plan *plan, const void *packed, const float *z, const float *mask,
+                              const float *mean, const float *ref, const float *ref_mask, const float *mean_ref,
+                              const float *c, const float *noise, float *out, void *workspace, size_t workspace_bytes, int B,
+                              int T, int T_ref, int n_timesteps, int mode, gtts_stream_t stream);
 
 /* ---- monotonic_align.maximum_path  monotonic_align/core.pyx:9-45 + __init__.py:8-23 ------------------- */
 /* value [b,tx,ty] fp32 (NOT modified), mask [b,tx,ty] fp32 or NULL, t_x / t_y [b] int32 device arrays,

@@ -23,7 +23,9 @@ class UnetCfg(ctypes.Structure):
     _fields_ = [("dim", ctypes.c_int), ("n_feats", ctypes.c_int), ("n_spks", ctypes.c_int),
                 ("spk_emb_dim", ctypes.c_int), ("groups", ctypes.c_int), ("pe_scale", ctypes.c_float),
                 ("beta_min", ctypes.c_float), ("beta_max", ctypes.c_float), ("precision", ctypes.c_int),
-                ("keep_intermediates", ctypes.c_int)]
+                ("keep_intermediates", ctypes.c_int), ("arch", ctypes.c_int), ("dim_cond", ctypes.c_int),
+                ("use_ref_t", ctypes.c_int), ("c_dim", ctypes.c_int), ("vc_beta_min", ctypes.c_double),
+                ("vc_beta_max", ctypes.c_double)]
 
 
 def lib():
@@ -61,6 +63,10 @@ def lib():
         L.gtts_plan_num_tensors.argtypes = [vp]
         L.gtts_plan_tensor_info.argtypes = [vp, i, i, i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz),
                                             ctypes.POINTER(i * 4)]
+        L.gtts_vc_workspace_bytes.argtypes = [vp, i, i, i]
+        L.gtts_vc_workspace_bytes.restype = sz
+        L.gtts_vc_estimator_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, i, vp]
+        L.gtts_vc_reverse_diffusion.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, i, i, i, vp]
         L.gtts_plan_num_ops.argtypes = [vp]
         L.gtts_plan_op_info.argtypes = [vp, i, i, i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p),
                                         ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
@@ -100,9 +106,12 @@ class Plan:
     """Host-side plan of one score U-Net (mirrors GradLogPEstimator2d.__init__, diffusion.py:129-172)."""
 
     def __init__(self, dim=64, n_feats=80, n_spks=1, spk_emb_dim=64, groups=8, pe_scale=1000.0, beta_min=0.05,
-                 beta_max=20.0, precision=PREC_BF16X3, keep_intermediates=False):
+                 beta_max=20.0, precision=PREC_BF16X3, keep_intermediates=False, arch=0, dim_cond=128, use_ref_t=True,
+                 c_dim=256):
+        """arch=0: Grad-TTS GradLogPEstimator2d; arch=1: DiffVC GradLogPEstimator (dim = dim_base)."""
         self.cfg = UnetCfg(int(dim), int(n_feats), int(n_spks), int(spk_emb_dim), int(groups), float(pe_scale),
-                           float(beta_min), float(beta_max), int(precision), 1 if keep_intermediates else 0)
+                           float(beta_min), float(beta_max), int(precision), 1 if keep_intermediates else 0, int(arch),
+                           int(dim_cond), 1 if use_ref_t else 0, int(c_dim), float(beta_min), float(beta_max))
         self._h = ctypes.c_void_p()
         _check(lib().gtts_plan_create(ctypes.byref(self.cfg), ctypes.byref(self._h)), "gtts_plan_create")
         self._ws = {}
@@ -204,6 +213,66 @@ class Plan:
                                                 _ptr(noise), _ptr(out), _ptr(ws), ws.numel(), B, T, int(n_timesteps),
                                                 _stream()), "gtts_reverse_diffusion")
         return out
+
+    # ---- DiffVC (arch=1)
+    def vc_workspace(self, B, T, Tr, device):
+        key = ("vc", int(B), int(T), int(Tr), str(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            self._ws.clear()
+            n = int(lib().gtts_vc_workspace_bytes(self._h, int(B), int(T), int(Tr)))
+            if n == 0:
+                raise RuntimeError("gtts_vc_workspace_bytes: %s" % lib().gtts_last_error().decode())
+            ws = torch.empty(n, dtype=torch.uint8, device=device)
+            self._ws[key] = ws
+        return ws
+
+    def vc_estimator_forward(self, blob, x, x_mask, mean, xt_ref, ref_mask, c, t):
+        """DiffVC GradLogPEstimator.forward(x, x_mask, mean, ref, ref_mask, c, t) (DiffVC/model/diffusion.py:61-106)."""
+        x, x_mask, mean, xt_ref, ref_mask, c, t = (_f32c(v, n) for v, n in (
+            (x, "x"), (x_mask, "x_mask"), (mean, "mean"), (xt_ref, "ref"), (ref_mask, "ref_mask"), (c, "c"), (t, "t")))
+        B, F, T = x.shape
+        Tr = int(ref_mask.shape[-1]) if ref_mask is not None else T
+        out = torch.empty_like(x)
+        ws = self.vc_workspace(B, T, Tr, x.device)
+        with torch.cuda.device(x.device):
+            _check(lib().gtts_vc_estimator_forward(self._h, _ptr(blob), _ptr(x), _ptr(x_mask), _ptr(mean), _ptr(xt_ref),
+                                                   _ptr(ref_mask), _ptr(c), _ptr(t), _ptr(out), _ptr(ws), ws.numel(), B, T, Tr,
+                                                   _stream()), "gtts_vc_estimator_forward")
+        return out
+
+    def vc_reverse_diffusion(self, blob, z, mask, mean, ref, ref_mask, mean_ref, c, n_timesteps, mode, noise=None):
+        """DiffVC Diffusion.reverse_diffusion (DiffVC/model/diffusion.py:164-196); mode in {'pf','em','ml'}."""
+        modes = {"pf": 0, "em": 1, "ml": 2}
+        if mode not in modes:
+            raise RuntimeError("mode must be one of pf / em / ml")
+        z, mask, mean, ref, ref_mask, mean_ref, c, noise = (_f32c(v, n) for v, n in (
+            (z, "z"), (mask, "mask"), (mean, "mean"), (ref, "ref"), (ref_mask, "ref_mask"), (mean_ref, "mean_ref"), (c, "c"),
+            (noise, "noise")))
+        B, F, T = z.shape
+        Tr = int(ref_mask.shape[-1]) if ref_mask is not None else T
+        if mode != "pf" and (noise is None or tuple(noise.shape) != (int(n_timesteps), B, F, T)):
+            raise RuntimeError("em / ml sampling needs noise of shape [n_timesteps, B, F, T]")
+        out = torch.empty_like(z)
+        ws = self.vc_workspace(B, T, Tr, z.device)
+        with torch.cuda.device(z.device):
+            _check(lib().gtts_vc_reverse_diffusion(self._h, _ptr(blob), _ptr(z), _ptr(mask), _ptr(mean), _ptr(ref),
+                                                   _ptr(ref_mask), _ptr(mean_ref), _ptr(c), _ptr(noise), _ptr(out), _ptr(ws),
+                                                   ws.numel(), B, T, Tr, int(n_timesteps), modes[mode], _stream()),
+                   "gtts_vc_reverse_diffusion")
+        return out
+
+    def vc_tensors(self, B, T, Tr, device):
+        """Named intermediates of the last DiffVC estimator call (keep_intermediates plans); ref tensors use T_ref."""
+        L = lib()
+        ws = self.vc_workspace(B, T, Tr, device)
+        out = {}
+        for k in range(L.gtts_plan_num_tensors(self._h)):
+            name, off, dims = ctypes.c_char_p(), ctypes.c_size_t(), (ctypes.c_int * 4)()
+            _check(L.gtts_plan_tensor_info(self._h, k, int(B), int(T), ctypes.byref(name), ctypes.byref(off),
+                                           ctypes.byref(dims)), "gtts_plan_tensor_info")
+            out[name.value.decode()] = (off.value, tuple(dims))
+        return ws, out
 
     # ---- measurement (bench.py): per-op HIP-event timing
     def ops(self, B, T):

@@ -46,7 +46,9 @@ enum ConvMode { CONV_C3 = 0, CONV_DN = 1, CONV_UP = 2, CONV_P1 = 3 };
 enum ConvPro {
     PRO_PLAIN = 0,   // v = x
     PRO_MASK = 1,    // v = x * mask                                   (Block input,    diffusion.py:57)
-    PRO_GN = 2       // v = (Mish(GN(x)) * mask + tbias) * mask        (block1 -> block2, diffusion.py:58,76,57)
+    PRO_GN = 2,      // v = (Mish(GN(x)) * mask + tbias) * mask        (block1 -> block2, diffusion.py:58,76,57)
+    PRO_IGLU = 3     // v = (IN(x[c]) * sigmoid(IN(x[c + cin])) + tbias) * mask   (DiffVC RefBlock: InstanceNorm + GLU,
+                     //      DiffVC/model/modules.py:140-157,160-165); the source tensor has 2*cin channels
 };
 enum ConvEpi {
     EPI_PLAIN = 0,   // out = acc + bias

@@ -51,14 +51,15 @@ struct ConvCfg {
     static_assert(WBLK16 % 256 == 0, "weight block must be a whole number of 256 x 16-byte rows");
 };
 
+static inline int conv_npar(int pro) { return pro == PRO_GN ? 3 : (pro == PRO_IGLU ? 5 : 0); }
 static inline size_t conv_smem_bytes(int npix, int nkg, int wblk16, int cin, int pro, int mt) {
     size_t cpad = (size_t)((cin + 8 * nkg - 1) / (8 * nkg)) * 8 * nkg;
-    return (size_t)npix * nkg * 16 * 2 + (size_t)wblk16 * 16 + (pro == PRO_GN ? 3 * cpad * 4 : 0) + 4 * 2 * 4 * 2 * 4 +
+    return (size_t)npix * nkg * 16 * 2 + (size_t)wblk16 * 16 + (size_t)conv_npar(pro) * cpad * 4 + 4 * 2 * 4 * 2 * 4 +
            (size_t)3 * mt * 4;
 }
 
 template <int MODE, int WM, int WN, int MF, int KCH, int PRO, int EPI, int NSPLIT>
-__global__ __launch_bounds__(256, GTTS_WAVES(MODE)) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void conv_mfma_kernel(const ConvArgs a) {
     using C = ConvCfg<MODE, WM, WN, MF, KCH>;
     constexpr int MT = C::MT, TR = C::TR, TC = C::TC, NST = C::NST, TPS = C::TPS, NKG = C::NKG;
     constexpr int HC = C::HC, NPIX = C::NPIX, AITER = C::AITER, WBLK16 = C::WBLK16, WITER = C::WITER;
@@ -68,8 +69,10 @@ __global__ __launch_bounds__(256, GTTS_WAVES(MODE)) void conv_mfma_kernel(const 
     u32x4 *s_al = s_ah + NKG * NPIX;                    // [NKG][NPIX]  lo
     u32x4 *s_w = s_al + NKG * NPIX;                     // [split][tap][kg][MT]
     const int cpad = a.nchunk * 8 * NKG;
-    float *s_par = reinterpret_cast<float *>(s_w + WBLK16);   // PRO_GN: [3][cpad] scale, shift, time bias
-    float *s_red = s_par + (PRO == PRO_GN ? 3 * cpad : 0);    // [4 waves][MF][4 octets][2]
+    // PRO_GN: [3][cpad] scale, shift, time bias; PRO_IGLU: [5][cpad] scale_a, shift_a, time bias, scale_b, shift_b
+    float *s_par = reinterpret_cast<float *>(s_w + WBLK16);
+    constexpr int NPAR = PRO == PRO_GN ? 3 : (PRO == PRO_IGLU ? 5 : 0);
+    float *s_red = s_par + NPAR * cpad;                       // [4 waves][MF][4 octets][2]
     float *s_epi = s_red + 4 * 2 * 4 * 2;                     // [3][MT]: bias, (EPI_TAIL) GN scale, shift
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -87,15 +90,21 @@ __global__ __launch_bounds__(256, GTTS_WAVES(MODE)) void conv_mfma_kernel(const 
     const int HWin = a.Hin * a.Win;
 
     // ---- per-(sample, channel) prologue parameters -> LDS (visible after the first barrier)
-    if (PRO == PRO_GN) {
+    if (PRO == PRO_GN || PRO == PRO_IGLU) {
+        const int cs = PRO == PRO_IGLU ? 2 * a.cin : a.cin;      // channels of the raw source tensor
         for (int i = tid; i < cpad; i += 256) {
             const bool ok = i < a.cin;
             const int ic = ok ? i : 0;
-            const float v0 = a.sc[(size_t)b * a.cin + ic], v1 = a.sh[(size_t)b * a.cin + ic];
-            const float v2 = a.tb[(size_t)b * a.tb_stride + ic];
+            const float v0 = a.sc[(size_t)b * cs + ic], v1 = a.sh[(size_t)b * cs + ic];
+            const float v2 = a.tb ? a.tb[(size_t)b * a.tb_stride + ic] : 0.f;
             s_par[i] = ok ? v0 : 0.f;
             s_par[cpad + i] = ok ? v1 : 0.f;
             s_par[2 * cpad + i] = ok ? v2 : 0.f;
+            if (PRO == PRO_IGLU) {
+                const float v3 = a.sc[(size_t)b * cs + a.cin + ic], v4 = a.sh[(size_t)b * cs + a.cin + ic];
+                s_par[3 * cpad + i] = ok ? v3 : 0.f;
+                s_par[4 * cpad + i] = ok ? v4 : 0.f;
+            }
         }
     }
 
@@ -129,6 +138,7 @@ __global__ __launch_bounds__(256, GTTS_WAVES(MODE)) void conv_mfma_kernel(const 
     }
 
     float araw[AITER][8];
+    float brawst[PRO == PRO_IGLU ? AITER : 1][8];      // PRO_IGLU: the gate half (channel c + cin)
     auto load_act = [&](int chunk) {
 #pragma unroll
         for (int it = 0; it < AITER; ++it) {
@@ -137,13 +147,16 @@ __global__ __launch_bounds__(256, GTTS_WAVES(MODE)) void conv_mfma_kernel(const 
             const int cbase = chunk * (8 * NKG) + kg * 8;
             const int nval = min(max(a.cin - cbase, 0), 8);        // valid channels of this 8-group
             const int cb0 = nval > 0 ? cbase : 0;
-            const float *pl = (cb0 < a.c0) ? a.src0 + ((size_t)b * a.c0 + cb0) * HWin
-                                           : a.src1 + ((size_t)b * a.c1 + (cb0 - a.c0)) * HWin;
+            const float *pl;
+            if (PRO == PRO_IGLU) pl = a.src0 + ((size_t)b * 2 * a.cin + cb0) * HWin;
+            else pl = (cb0 < a.c0) ? a.src0 + ((size_t)b * a.c0 + cb0) * HWin
+                                   : a.src1 + ((size_t)b * a.c1 + (cb0 - a.c0)) * HWin;
             pl += it_goff[it];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int ii = min(i, max(nval, 1) - 1);            // clamp: always a valid address
                 araw[it][i] = pl[(size_t)ii * HWin];                 // zeroing of i >= nval happens at use
+                if (PRO == PRO_IGLU) brawst[it][i] = pl[(size_t)(ii + a.cin) * HWin];
             }
         }
     };
@@ -187,8 +200,8 @@ __global__ __launch_bounds__(256, GTTS_WAVES(MODE)) void conv_mfma_kernel(const 
             const float m = inb ? mraw : 0.f;
             const int cb = chunk * (8 * NKG) + kg * 8;
             const int nval = min(max(a.cin - cb, 0), 8);
-            float sc[8], sh[8], tb[8];
-            if (PRO == PRO_GN) {
+            float sc[8], sh[8], tb[8], scb[8], shb[8];
+            if (PRO == PRO_GN || PRO == PRO_IGLU) {
                 const float4 *q = reinterpret_cast<const float4 *>(s_par + cb);
                 const float4 *q1 = reinterpret_cast<const float4 *>(s_par + cpad + cb);
                 const float4 *q2 = reinterpret_cast<const float4 *>(s_par + 2 * cpad + cb);
@@ -198,6 +211,16 @@ __global__ __launch_bounds__(256, GTTS_WAVES(MODE)) void conv_mfma_kernel(const 
                     sc[4 * h + 0] = u.x; sc[4 * h + 1] = u.y; sc[4 * h + 2] = u.z; sc[4 * h + 3] = u.w;
                     sh[4 * h + 0] = u1.x; sh[4 * h + 1] = u1.y; sh[4 * h + 2] = u1.z; sh[4 * h + 3] = u1.w;
                     tb[4 * h + 0] = u2.x; tb[4 * h + 1] = u2.y; tb[4 * h + 2] = u2.z; tb[4 * h + 3] = u2.w;
+                }
+                if (PRO == PRO_IGLU) {
+                    const float4 *q3 = reinterpret_cast<const float4 *>(s_par + 3 * cpad + cb);
+                    const float4 *q4 = reinterpret_cast<const float4 *>(s_par + 4 * cpad + cb);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float4 u3 = q3[h], u4 = q4[h];
+                        scb[4 * h + 0] = u3.x; scb[4 * h + 1] = u3.y; scb[4 * h + 2] = u3.z; scb[4 * h + 3] = u3.w;
+                        shb[4 * h + 0] = u4.x; shb[4 * h + 1] = u4.y; shb[4 * h + 2] = u4.z; shb[4 * h + 3] = u4.w;
+                    }
                 }
             }
             bf16x8 vh, vl;
@@ -209,6 +232,11 @@ __global__ __launch_bounds__(256, GTTS_WAVES(MODE)) void conv_mfma_kernel(const 
                 } else if (PRO == PRO_GN) {
                     const float y = v * sc[i] + sh[i];
                     v = (mish_f(y) * m + tb[i]) * m;
+                } else if (PRO == PRO_IGLU) {
+                    const float ga = v * sc[i] + sh[i];
+                    const float gb = brawst[it][i] * scb[i] + shb[i];
+                    const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-gb));     // sigmoid
+                    v = (inb && i < nval) ? (ga * sg + tb[i]) * m : 0.f;
                 }
                 __bf16 h, l;
                 split_bf16(v, h, l);
@@ -743,7 +771,7 @@ static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
         if (e != hipSuccess) return e;
         attr_set = smem;
     }
-    if ((MODE == CONV_C3 || MODE == CONV_UP) && conv_pipe_enabled()) {
+    if constexpr ((MODE == CONV_C3 && EPI == EPI_STATS) || MODE == CONV_UP) if (conv_pipe_enabled()) {
         size_t smem2 = conv_pipe_smem_bytes(C::NPIX, C::NKG, C::WBLK16, a.cin, PRO, C::MT);
         static size_t attr2 = 0;
         if (smem2 > attr2) {
@@ -779,6 +807,15 @@ hipError_t launch_conv(int mode, const ConvArgs &a, hipStream_t st) {
     const bool wide = a.cout > 64;
     switch (mode) {
         case CONV_C3:
+            if (a.epi == EPI_PLAIN) {          // DiffVC RefBlock convolutions (InstanceNorm statistics are a separate pass)
+                if (a.pro == PRO_MASK)
+                    return wide ? launch_prec<CONV_C3, 2, 2, 2, PRO_MASK, EPI_PLAIN>(a, st)
+                                : launch_prec<CONV_C3, 1, 4, 2, PRO_MASK, EPI_PLAIN>(a, st);
+                if (a.pro == PRO_IGLU)
+                    return wide ? launch_prec<CONV_C3, 2, 2, 2, PRO_IGLU, EPI_PLAIN>(a, st)
+                                : launch_prec<CONV_C3, 1, 4, 2, PRO_IGLU, EPI_PLAIN>(a, st);
+                break;
+            }
             if (a.epi != EPI_STATS) break;
             if (a.pro == PRO_MASK)
                 return wide ? launch_prec<CONV_C3, 2, 2, 2, PRO_MASK, EPI_STATS>(a, st)

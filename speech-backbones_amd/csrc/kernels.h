@@ -12,8 +12,18 @@ struct TimeMlpDesc {
     int cout[32];
     size_t w[32], b[32];     // blob byte offsets of <R>.mlp.1.{weight,bias}
     int off[32];             // column of the block's bias vector inside a tb row
-    int temb_off;            // column where the raw time embedding (dim floats) is stored
+    int temb_off;            // column where the time embedding t = mlp(emb) (dim floats) is stored
+    int semb_off;            // column where the raw sinusoidal embedding (dim floats) is stored, -1: not stored
     int tb_stride;
+};
+
+// one reverse step of the DiffVC sampler (DiffVC/model/diffusion.py:177-195); mode 0 = Grad-TTS Euler(-Maruyama)
+struct VcStep {
+    int mode;                // 1: 'pf', 2: 'em' / 'ml'
+    float cm;                // 0.5*beta*h + omega
+    float k1;                // 1 + kappa
+    float bh;                // beta*h
+    float sigma;
 };
 
 hipError_t launch_prep_input(const float *mu, const float *x, const float *s, float *x0, int B, int F, int T,
@@ -31,7 +41,21 @@ hipError_t launch_euler_step(float *xt, const float *mu, const float *est, const
 hipError_t launch_mul_mask(const float *z, const float *mask, float *out, int B, int F, int T, hipStream_t st);
 hipError_t launch_final_euler(const float *raw, const float *sc, const float *sh, const float *w, const float *bias,
                               const float *mask, int B, int C, int F, int T, float *est_out, float *xt, const float *mu,
-                              const float *noise, float beta, float h, hipStream_t st);
+                              const float *noise, float beta, float h, hipStream_t st, const VcStep *vc = nullptr);
+
+// ---- vc.hip  (DiffVC-only pieces: RefBlock statistics / pooling, condition MLP, input assembly)
+hipError_t launch_xt_ref(const float *ref, const float *mean_ref, const float *ref_mask, float *out, float w0, float w1,
+                         int B, int F, int Tr, hipStream_t st);
+hipError_t launch_instnorm_stats(const float *x, const float *gamma, const float *beta, float *sc, float *sh, int B, int C,
+                                 int HW, hipStream_t st);
+hipError_t launch_ref_pool(const float *raw, const float *sc, const float *sh, const float *ref_mask, float *S, int B,
+                           int Ch, int F, int Tr, hipStream_t st);
+hipError_t launch_vc_cond(const float *tb, int tb_stride, int semb_off, int dim, const float *S, const float *ref_mask,
+                          const float *fw, const float *fb, const float *c, const float *w0, const float *b0,
+                          const float *w2, const float *b2, float *cond, int B, int Ch, int dim_cond, int cdim, int F, int Tr,
+                          int use_ref, hipStream_t st);
+hipError_t launch_prep_vc(const float *mean, const float *x, const float *cond, float *x0, int B, int F, int T, int ncond,
+                          hipStream_t st);
 
 // ---- conv_mfma.hip
 int conv_nparts(int mode, int cout, int Hout, int Wout);

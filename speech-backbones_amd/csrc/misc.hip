@@ -71,8 +71,13 @@ __global__ void time_mlp_kernel(const float *__restrict__ t, const float *__rest
     const float tv = t[row];
     for (int k = threadIdx.x; k < half; k += blockDim.x) {
         const float arg = __fmul_rn(__fmul_rn(pe_scale, tv), freq[k]);   // scale * x * emb  (diffusion.py:123)
-        emb[k] = sinf(arg);
-        emb[half + k] = cosf(arg);
+        const float sv = sinf(arg), cv = cosf(arg);
+        emb[k] = sv;
+        emb[half + k] = cv;
+        if (d.semb_off >= 0) {                                            // DiffVC: `condition` starts with it
+            tb[(size_t)row * d.tb_stride + d.semb_off + k] = sv;
+            tb[(size_t)row * d.tb_stride + d.semb_off + half + k] = cv;
+        }
     }
     __syncthreads();
     const float *w0 = reinterpret_cast<const float *>(blob + d.w0), *b0 = reinterpret_cast<const float *>(blob + d.b0);
@@ -244,11 +249,27 @@ hipError_t launch_mul_mask(const float *z, const float *mask, float *out, int B,
 // ------------------------------------------------------------------------------------------------ final_euler
 // est = (sum_c w[c] * (Mish(GN(raw[c])) * m) * m + bias) * m        (final_block :56-58, final_conv :214-216)
 // then optionally the Euler update of xt in the same pass (est never touches HBM inside the sampling loop).
+// DiffVC update (DiffVC/model/diffusion.py:177-195), same fp32 operation order as the reference's tensor math:
+//   pf:     dxt = 0.5*(mean - xt - est) * (beta*h)
+//   em/ml:  dxt = (mean - xt)*cm;  dxt -= est*k1*bh;  dxt += randn*sigma          xt = (xt - dxt)*mask
+__device__ __forceinline__ float vc_update(float xt, float mean, float est, float m, float noise, int mode, float cm,
+                                           float k1, float bh, float sigma) {
+    float dxt;
+    if (mode == 1) {
+        dxt = __fmul_rn(__fmul_rn(0.5f, __fsub_rn(__fsub_rn(mean, xt), est)), bh);
+    } else {
+        dxt = __fmul_rn(__fsub_rn(mean, xt), cm);
+        dxt = __fsub_rn(dxt, __fmul_rn(__fmul_rn(est, k1), bh));
+        dxt = __fadd_rn(dxt, __fmul_rn(noise, sigma));
+    }
+    return __fmul_rn(__fsub_rn(xt, dxt), m);
+}
+
 __global__ void final_euler_kernel(const float *__restrict__ raw, const float *__restrict__ sc,
                                    const float *__restrict__ sh, const float *__restrict__ w, const float *__restrict__ bias,
                                    const float *__restrict__ mask, int C, int F, int T, float *__restrict__ est_out,
                                    float *__restrict__ xt, const float *__restrict__ mu, const float *__restrict__ noise,
-                                   float beta, float h, float sq) {
+                                   float beta, float h, float sq, VcStep vc) {
     extern __shared__ float sm[];     // [3][C]: scale, shift, weight
     const int b = blockIdx.y;
     for (int i = threadIdx.x; i < C; i += 256) {
@@ -271,16 +292,22 @@ __global__ void final_euler_kernel(const float *__restrict__ raw, const float *_
     const float est = (acc + bias[0]) * m;
     const size_t o = (size_t)b * FT + i;
     if (est_out) est_out[o] = est;
-    if (xt) xt[o] = euler_update(xt[o], mu[o], est, m, noise ? noise[o] : 0.f, noise != nullptr, beta, h, sq);
+    if (xt) {
+        if (vc.mode == 0) xt[o] = euler_update(xt[o], mu[o], est, m, noise ? noise[o] : 0.f, noise != nullptr, beta, h, sq);
+        else xt[o] = vc_update(xt[o], mu[o], est, m, noise ? noise[o] : 0.f, vc.mode, vc.cm, vc.k1, vc.bh, vc.sigma);
+    }
 }
 
 hipError_t launch_final_euler(const float *raw, const float *sc, const float *sh, const float *w, const float *bias,
                               const float *mask, int B, int C, int F, int T, float *est_out, float *xt, const float *mu,
-                              const float *noise, float beta, float h, hipStream_t st) {
+                              const float *noise, float beta, float h, hipStream_t st, const VcStep *vc) {
     dim3 grid((F * T + 255) / 256, B);
     const float sq = sqrtf(beta * h);
+    VcStep v;
+    v.mode = 0; v.cm = v.k1 = v.bh = v.sigma = 0.f;
+    if (vc) v = *vc;
     hipLaunchKernelGGL(final_euler_kernel, grid, dim3(256), (size_t)3 * C * sizeof(float), st, raw, sc, sh, w, bias,
-                       mask, C, F, T, est_out, xt, mu, noise, beta, h, sq);
+                       mask, C, F, T, est_out, xt, mu, noise, beta, h, sq, v);
     return hipGetLastError();
 }
 

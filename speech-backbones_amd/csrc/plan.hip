@@ -50,10 +50,11 @@ struct Tensor {
     size_t bytes;   // TK_BYTES_PERB
     int mode, cout; // TK_PART: conv geometry that produces it
     bool external;  // not in the workspace (inputs / outputs of the call)
+    bool tref;      // frame axis is the reference mel's (T_ref) instead of T  (DiffVC RefBlock tensors)
     int first, last;
 };
 
-enum OpKind { OP_CONV, OP_GNFIN, OP_TAILID, OP_ACTX, OP_AMERGE, OP_AFOLD };
+enum OpKind { OP_CONV, OP_GNFIN, OP_TAILID, OP_ACTX, OP_AMERGE, OP_AFOLD, OP_INSTATS, OP_REFPOOL, OP_VCCOND, OP_PREPVC };
 struct Op {
     int kind;
     // conv
@@ -69,6 +70,8 @@ struct Op {
     // attention
     size_t wkv_off, wq_off, wout_off, bout_off, g_off;
     int apart, ctxn;
+    int use_ref;                   // conv / stats run on the reference mel geometry (ref_mask, T_ref)
+    int has_tb;                    // PRO_IGLU: a time bias column is added (tb_off valid)
     std::string label;
 };
 
@@ -96,6 +99,8 @@ struct gtts_plan {
     std::vector<Tensor> tensors;
     std::vector<Op> ops;
     int t_x0, t_s, t_tb, t_final_raw, t_final_sc, t_final_sh;
+    int t_xtref = -1, t_cond = -1;   // DiffVC: diffused reference mel [B,1,F,T_ref], condition vector [B,dim_cond]
+    int cache_Tr = -1;
     size_t fw_off, fb_off;     // final_conv weight / bias (fp32)
     // extra (non-program) launches, profiled as ops n_ops .. n_ops+3: prep_input, time_mlp, final_euler, mul_mask
     // profiling
@@ -148,7 +153,7 @@ static size_t poff(const gtts_plan *p, const std::string &name) { return p->para
 static int add_tensor(gtts_plan *p, const std::string &name, int kind, int C, int lvl, bool external = false) {
     Tensor t;
     t.name = name; t.kind = kind; t.C = C; t.lvl = lvl; t.bytes = 0; t.mode = 0; t.cout = 0;
-    t.external = external; t.first = 1 << 30; t.last = -1;
+    t.external = external; t.tref = false; t.first = 1 << 30; t.last = -1;
     p->tensors.push_back(t);
     return (int)p->tensors.size() - 1;
 }
@@ -158,7 +163,7 @@ static Op blank_op(int kind, const std::string &label) {
     o.kind = kind; o.mode = 0; o.pro = 0; o.epi = 0; o.src0 = o.src1 = -1; o.c0 = o.c1 = 0; o.cout = 0;
     o.lvl_in = o.lvl_out = 0; o.sc = o.sh = -1; o.tb_off = 0; o.w_off = o.b_off = 0; o.w_t = o.bias_t = -1;
     o.out = o.part = o.eh = o.esc = o.esh = o.eres = -1; o.C = 0; o.gamma_off = o.beta_off = 0;
-    o.wkv_off = o.wq_off = o.wout_off = o.bout_off = o.g_off = 0; o.apart = o.ctxn = -1;
+    o.wkv_off = o.wq_off = o.wout_off = o.bout_off = o.g_off = 0; o.apart = o.ctxn = -1; o.use_ref = 0; o.has_tb = 0;
     o.label = label;
     return o;
 }
@@ -291,7 +296,7 @@ static void compute_liveness(gtts_plan *p) {
     }
     const int n = (int)p->ops.size();
     // tensors used outside the op program: alive for the whole call
-    for (int t : {p->t_x0, p->t_s, p->t_tb, p->t_final_raw, p->t_final_sc, p->t_final_sh}) {
+    for (int t : {p->t_x0, p->t_s, p->t_tb, p->t_final_raw, p->t_final_sc, p->t_final_sh, p->t_xtref, p->t_cond}) {
         if (t < 0) continue;
         p->tensors[t].first = -1;
         p->tensors[t].last = n + 1;
@@ -314,8 +319,14 @@ extern "C" int gtts_plan_create(const gtts_unet_cfg *cfg, gtts_plan **out) {
     p->blob_bytes = 0;
     p->nlev = 3;
     const int dim = cfg->dim;
+    const bool vc = cfg->arch == 1;
+    if (cfg->arch != 0 && cfg->arch != 1) { delete p; return fail(GTTS_E_CONFIG, "unknown arch %d", cfg->arch); }
+    if (vc && (cfg->dim_cond <= 0 || cfg->dim_cond % 32 != 0 || cfg->c_dim <= 0 || cfg->n_spks != 1)) {
+        delete p;
+        return fail(GTTS_E_CONFIG, "DiffVC plan needs dim_cond %% 32 == 0, c_dim > 0, n_spks == 1");
+    }
     const bool multi = cfg->n_spks > 1;
-    p->cin0 = 2 + (multi ? 1 : 0);
+    p->cin0 = vc ? 2 + cfg->dim_cond : 2 + (multi ? 1 : 0);
     p->dims[0] = p->cin0; p->dims[1] = dim; p->dims[2] = 2 * dim; p->dims[3] = 4 * dim;
     memset(&p->tmlp, 0, sizeof(p->tmlp));
     p->tmlp.dim = dim;
@@ -343,6 +354,80 @@ extern "C" int gtts_plan_create(const gtts_unet_cfg *cfg, gtts_plan **out) {
     p->t_x0 = add_tensor(p, "x0", TK_ACT, p->cin0, 0);
     p->t_s = multi ? add_tensor(p, "spk_s", TK_PERB, cfg->n_feats, 0) : -1;
     p->t_tb = add_tensor(p, "tb", TK_ROWS, 0, 0);
+    p->tmlp.semb_off = -1;
+
+    if (vc) {
+        // ---- DiffVC pre-trunk: RefBlock (modules.py:128-166), cond_block, 130-channel input (diffusion.py:62-76)
+        const int dc = cfg->dim_cond, base = dc / 4;
+        int S = -1;
+        if (cfg->use_ref_t) {
+            TimeMlpDesc &tm = p->tmlp;
+            int tboff[2];
+            const char *mn[2] = {"ref_block.mlp1.1", "ref_block.mlp2.1"};
+            const int mc[2] = {base, 2 * base};
+            for (int k = 0; k < 2; ++k) {
+                add_param(p, std::string(mn[k]) + ".weight", {mc[k], dim}, 0);
+                add_param(p, std::string(mn[k]) + ".bias", {mc[k]}, 0);
+                const int r = tm.n++;
+                tm.cout[r] = mc[k];
+                tm.w[r] = poff(p, std::string(mn[k]) + ".weight");
+                tm.b[r] = poff(p, std::string(mn[k]) + ".bias");
+                tm.off[r] = r == 0 ? 0 : tm.off[r - 1] + tm.cout[r - 1];
+                tboff[k] = tm.off[r];
+            }
+            p->t_xtref = add_tensor(p, "xt_ref", TK_ACT, 1, 0);
+            p->tensors[p->t_xtref].tref = true;
+            struct RB { const char *name; int cin, cout, tbk; };
+            const RB rb[6] = {{"block11", 1, 2 * base, -1}, {"block12", base, 2 * base, -1}, {"block21", base, 4 * base, 0},
+                              {"block22", 2 * base, 4 * base, -1}, {"block31", 2 * base, 8 * base, 1}, {"block32", 4 * base, 8 * base, -1}};
+            int prev_raw = p->t_xtref, prev_sc = -1, prev_sh = -1;
+            for (int k = 0; k < 6; ++k) {
+                const std::string pre = std::string("ref_block.") + rb[k].name + ".";
+                add_param(p, pre + "0.weight", {rb[k].cout, rb[k].cin, 3, 3}, 1, rb[k].cin, rb[k].cout);
+                add_param(p, pre + "0.bias", {rb[k].cout}, 0);
+                add_param(p, pre + "1.weight", {rb[k].cout}, 0);
+                add_param(p, pre + "1.bias", {rb[k].cout}, 0);
+                const int raw = add_tensor(p, std::string("ref.") + rb[k].name + ".raw", TK_ACT, rb[k].cout, 0);
+                p->tensors[raw].tref = true;
+                const int sc = add_tensor(p, std::string("ref.") + rb[k].name + ".sc", TK_PERB, rb[k].cout, 0);
+                const int sh = add_tensor(p, std::string("ref.") + rb[k].name + ".sh", TK_PERB, rb[k].cout, 0);
+                Op c = blank_op(OP_CONV, std::string("ref.") + rb[k].name + ".conv");
+                c.mode = CONV_C3; c.epi = EPI_PLAIN; c.use_ref = 1;
+                c.pro = k == 0 ? PRO_MASK : PRO_IGLU;
+                c.src0 = prev_raw; c.c0 = rb[k].cin; c.cout = rb[k].cout;
+                c.sc = prev_sc; c.sh = prev_sh;
+                if (rb[k].tbk >= 0) { c.has_tb = 1; c.tb_off = tboff[rb[k].tbk]; }
+                c.w_off = poff(p, pre + "0.weight"); c.b_off = poff(p, pre + "0.bias"); c.out = raw;
+                p->ops.push_back(c);
+                Op st = blank_op(OP_INSTATS, std::string("ref.") + rb[k].name + ".in");
+                st.src0 = raw; st.C = rb[k].cout; st.use_ref = 1; st.sc = sc; st.sh = sh;
+                st.gamma_off = poff(p, pre + "1.weight"); st.beta_off = poff(p, pre + "1.bias");
+                p->ops.push_back(st);
+                prev_raw = raw; prev_sc = sc; prev_sh = sh;
+            }
+            add_param(p, "ref_block.final_conv.weight", {dc, 4 * base, 1, 1}, 0);
+            add_param(p, "ref_block.final_conv.bias", {dc}, 0);
+            S = add_tensor(p, "ref.pool", TK_PERB, 4 * base, 0);
+            Op rp = blank_op(OP_REFPOOL, "ref.pool");
+            rp.src0 = prev_raw; rp.sc = prev_sc; rp.sh = prev_sh; rp.C = 4 * base; rp.out = S; rp.use_ref = 1;
+            p->ops.push_back(rp);
+        }
+        const int nin = dim + (cfg->use_ref_t ? dc : 0) + cfg->c_dim;
+        add_param(p, "cond_block.0.weight", {4 * dc, nin}, 0);
+        add_param(p, "cond_block.0.bias", {4 * dc}, 0);
+        add_param(p, "cond_block.2.weight", {dc, 4 * dc}, 0);
+        add_param(p, "cond_block.2.bias", {dc}, 0);
+        p->t_cond = add_tensor(p, "cond", TK_PERB, dc, 0);
+        Op cd = blank_op(OP_VCCOND, "cond_block");
+        cd.src0 = S; cd.C = 4 * base; cd.out = p->t_cond;
+        if (cfg->use_ref_t) { cd.w_off = poff(p, "ref_block.final_conv.weight"); cd.b_off = poff(p, "ref_block.final_conv.bias"); }
+        cd.wq_off = poff(p, "cond_block.0.weight"); cd.wout_off = poff(p, "cond_block.0.bias");
+        cd.bout_off = poff(p, "cond_block.2.weight"); cd.g_off = poff(p, "cond_block.2.bias");
+        p->ops.push_back(cd);
+        Op pv = blank_op(OP_PREPVC, "prep_input");
+        pv.src0 = p->t_cond; pv.out = p->t_x0;
+        p->ops.push_back(pv);
+    }
 
     // The U-Net is *executed* downs -> mid -> ups -> final, but `ups` is registered before `mid_*`
     // (diffusion.py:148-149: the empty ModuleList is created first).  Parameter order below follows execution;
@@ -400,6 +485,7 @@ extern "C" int gtts_plan_create(const gtts_unet_cfg *cfg, gtts_plan **out) {
     TimeMlpDesc &tm = p->tmlp;
     tm.temb_off = tm.n ? tm.off[tm.n - 1] + tm.cout[tm.n - 1] : 0;
     tm.tb_stride = tm.temb_off + dim;
+    if (vc) { tm.semb_off = tm.tb_stride; tm.tb_stride += dim; }
     if (tm.n > 32) { delete p; return fail(GTTS_E_CONFIG, "too many ResnetBlocks"); }
     for (const Op &o : p->ops)
         if (o.kind == OP_CONV && o.c1 > 0 && (o.c0 % 8) != 0) { delete p; return fail(GTTS_E_CONFIG, "concat split must be a multiple of 8 channels"); }
@@ -434,6 +520,8 @@ static int sampler_streams() {
 static int reg_rank(const std::string &n) {
     if (n.rfind("spk_mlp", 0) == 0) return 0;
     if (n.rfind("mlp.", 0) == 0) return 1;
+    if (n.rfind("ref_block", 0) == 0) return 1;     // DiffVC: mlp, ref_block, cond_block precede the trunk, in this order
+    if (n.rfind("cond_block", 0) == 0) return 1;
     if (n.rfind("downs", 0) == 0) return 2;
     if (n.rfind("ups", 0) == 0) return 3;
     if (n.rfind("mid_block1", 0) == 0) return 4;
@@ -494,9 +582,9 @@ extern "C" int gtts_pack_weights(const gtts_plan *plan, const void *const *param
 }
 
 // ------------------------------------------------------------------------------------------------ workspace
-static size_t tensor_bytes(const gtts_plan *p, const Tensor &t, int B, int T, int rows) {
+static size_t tensor_bytes(const gtts_plan *p, const Tensor &t, int B, int T, int rows, int Tr) {
     const int F = p->cfg.n_feats;
-    const size_t H = (size_t)F >> t.lvl, W = (size_t)T >> t.lvl;
+    const size_t H = (size_t)F >> t.lvl, W = (size_t)(t.tref ? Tr : T) >> t.lvl;
     switch (t.kind) {
         case TK_ACT: return (size_t)B * t.C * H * W * 4;
         case TK_PERB: return (size_t)B * t.C * 4;
@@ -509,12 +597,14 @@ static size_t tensor_bytes(const gtts_plan *p, const Tensor &t, int B, int T, in
 }
 
 // (B,T) -> offsets.  keep_intermediates: every tensor gets its own slot; otherwise first-fit reuse by liveness.
-static void layout_workspace(gtts_plan *p, int B, int T, int rows) {
-    if (p->cache_B == B && p->cache_T == T * 4096 + rows) return;
+static void layout_workspace(gtts_plan *p, int B, int T, int rows, int Tr = 0) {
+    if (Tr <= 0) Tr = T;
+    if (p->cache_B == B && p->cache_T == T * 4096 + rows && p->cache_Tr == Tr) return;
+    p->cache_Tr = Tr;
     const int n = (int)p->tensors.size();
     p->offsets.assign(n, 0);
     std::vector<size_t> sz(n);
-    for (int i = 0; i < n; ++i) sz[i] = align_up(tensor_bytes(p, p->tensors[i], B, T, rows), 256);
+    for (int i = 0; i < n; ++i) sz[i] = align_up(tensor_bytes(p, p->tensors[i], B, T, rows, Tr), 256);
     size_t top = 0;
     if (p->cfg.keep_intermediates) {
         for (int i = 0; i < n; ++i) { p->offsets[i] = top; top += sz[i]; }
@@ -595,6 +685,10 @@ struct RunCtx {
     const float *tb_row;   // tb rows of this call
     int tb_bstride;        // floats between samples' rows (0: one row shared by the batch)
     hipStream_t st;
+    // DiffVC extras
+    const float *ref_mask = nullptr;
+    int Tr = 0;
+    const float *in_x = nullptr, *in_mean = nullptr, *in_c = nullptr;
 };
 
 enum { XOP_PREP = 0, XOP_TIME = 1, XOP_FINAL = 2, XOP_MULMASK = 3, XOP_SPK = 4, XOP_COUNT = 5 };
@@ -631,12 +725,14 @@ static int run_ops(const RunCtx &c) {
                 a.src1 = o.src1 >= 0 ? tptr(c, o.src1) : a.src0;
                 a.c0 = o.c0; a.c1 = o.c1; a.cin = o.c0 + o.c1; a.nchunk = 0;
                 a.B = c.B;
-                a.Hin = F >> o.lvl_in; a.Win = c.T >> o.lvl_in;
-                a.Hout = F >> o.lvl_out; a.Wout = c.T >> o.lvl_out;
-                a.mask = c.mask; a.T = c.T; a.lvl_in = o.lvl_in; a.lvl_out = o.lvl_out;
+                const int Tw = o.use_ref ? c.Tr : c.T;
+                a.Hin = F >> o.lvl_in; a.Win = Tw >> o.lvl_in;
+                a.Hout = F >> o.lvl_out; a.Wout = Tw >> o.lvl_out;
+                a.mask = o.use_ref ? c.ref_mask : c.mask; a.T = Tw; a.lvl_in = o.lvl_in; a.lvl_out = o.lvl_out;
                 a.pro = o.pro;
                 a.sc = tptr(c, o.sc); a.sh = tptr(c, o.sh);
                 a.tb = c.tb_row + o.tb_off; a.tb_stride = c.tb_bstride;
+                if (o.pro == PRO_IGLU && !o.has_tb) a.tb = nullptr;
                 if (o.w_t >= 0) {
                     a.w = (const unsigned char *)tptr(c, o.w_t);
                     a.w_bstride = p->tensors[o.w_t].bytes;
@@ -685,6 +781,33 @@ static int run_ops(const RunCtx &c) {
                 if (e != hipSuccess) return fail(GTTS_E_HIP, "attn_merge %s: %s", o.label.c_str(), hipGetErrorString(e));
                 break;
             }
+            case OP_INSTATS: {
+                const int HW = (F >> o.lvl_in) * ((o.use_ref ? c.Tr : c.T) >> o.lvl_in);
+                hipError_t e = launch_instnorm_stats(tptr(c, o.src0), (const float *)(c.blob + o.gamma_off),
+                                                     (const float *)(c.blob + o.beta_off), tptr(c, o.sc), tptr(c, o.sh), c.B, o.C, HW, c.st);
+                if (e != hipSuccess) return fail(GTTS_E_HIP, "instnorm_stats %s: %s", o.label.c_str(), hipGetErrorString(e));
+                break;
+            }
+            case OP_REFPOOL: {
+                hipError_t e = launch_ref_pool(tptr(c, o.src0), tptr(c, o.sc), tptr(c, o.sh), c.ref_mask, tptr(c, o.out), c.B, o.C, F, c.Tr, c.st);
+                if (e != hipSuccess) return fail(GTTS_E_HIP, "ref_pool: %s", hipGetErrorString(e));
+                break;
+            }
+            case OP_VCCOND: {
+                const gtts_unet_cfg &cf = p->cfg;
+                hipError_t e = launch_vc_cond(c.tb_row, c.tb_bstride, p->tmlp.semb_off, cf.dim, tptr(c, o.src0), c.ref_mask,
+                                              (const float *)(c.blob + o.w_off), (const float *)(c.blob + o.b_off), c.in_c,
+                                              (const float *)(c.blob + o.wq_off), (const float *)(c.blob + o.wout_off),
+                                              (const float *)(c.blob + o.bout_off), (const float *)(c.blob + o.g_off), tptr(c, o.out),
+                                              c.B, o.C, cf.dim_cond, cf.c_dim, F, c.Tr, cf.use_ref_t, c.st);
+                if (e != hipSuccess) return fail(GTTS_E_HIP, "vc_cond: %s", hipGetErrorString(e));
+                break;
+            }
+            case OP_PREPVC: {
+                hipError_t e = launch_prep_vc(c.in_mean, c.in_x, tptr(c, o.src0), tptr(c, o.out), c.B, F, c.T, p->cfg.dim_cond, c.st);
+                if (e != hipSuccess) return fail(GTTS_E_HIP, "prep_vc: %s", hipGetErrorString(e));
+                break;
+            }
             case OP_AFOLD: {
                 hipError_t e = launch_attn_fold(tptr(c, o.ctxn), (const float *)(c.blob + o.wq_off),
                                                 (const float *)(c.blob + o.wout_off), (const float *)(c.blob + o.bout_off),
@@ -717,6 +840,7 @@ extern "C" int gtts_estimator_forward(const gtts_plan *plan, const void *packed,
     int rc = check_shape(plan, B, T);
     if (rc) return rc;
     if (!packed || !x || !mask || !mu || !t || !out || !workspace) return fail(GTTS_E_NULL, "gtts_estimator_forward: null argument");
+    if (plan->cfg.arch != 0) return fail(GTTS_E_CONFIG, "gtts_estimator_forward needs a Grad-TTS plan (arch 0); use gtts_vc_estimator_forward");
     gtts_plan *p = const_cast<gtts_plan *>(plan);
     const bool multi = p->cfg.n_spks > 1;
     if (multi && !spk) return fail(GTTS_E_NULL, "multi-speaker plan needs spk");
@@ -760,6 +884,7 @@ extern "C" int gtts_reverse_diffusion(const gtts_plan *plan, const void *packed,
     if (rc) return rc;
     if (!packed || !z || !mask || !mu || !out || !workspace) return fail(GTTS_E_NULL, "gtts_reverse_diffusion: null argument");
     if (n_timesteps <= 0 || n_timesteps > 4096) return fail(GTTS_E_SHAPE, "n_timesteps must be in [1, 4096], got %d", n_timesteps);
+    if (plan->cfg.arch != 0) return fail(GTTS_E_CONFIG, "gtts_reverse_diffusion needs a Grad-TTS plan (arch 0); use gtts_vc_reverse_diffusion");
     gtts_plan *p = const_cast<gtts_plan *>(plan);
     const bool multi = p->cfg.n_spks > 1;
     if (multi && !spk) return fail(GTTS_E_NULL, "multi-speaker plan needs spk");
@@ -846,6 +971,131 @@ extern "C" int gtts_reverse_diffusion(const gtts_plan *plan, const void *packed,
     return GTTS_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ DiffVC
+static int vc_check(const gtts_plan *plan, int B, int T, int Tr) {
+    int rc = check_shape(plan, B, T);
+    if (rc) return rc;
+    if (plan->cfg.arch != 1) return fail(GTTS_E_CONFIG, "a DiffVC plan (arch 1) is required");
+    if (Tr <= 0) return fail(GTTS_E_SHAPE, "T_ref must be positive (got %d)", Tr);
+    return GTTS_OK;
+}
+
+extern "C" size_t gtts_vc_workspace_bytes(const gtts_plan *plan, int B, int T, int T_ref) {
+    if (vc_check(plan, B, T, T_ref) != GTTS_OK) return 0;
+    gtts_plan *p = const_cast<gtts_plan *>(plan);
+    layout_workspace(p, B, T, std::max(B, 4096), T_ref);
+    return p->ws_bytes;
+}
+
+extern "C" int gtts_vc_estimator_forward(const gtts_plan *plan, const void *packed, const float *x, const float *x_mask,
+                                         const float *mean, const float *xt_ref, const float *ref_mask, const float *c,
+                                         const float *t, float *out, void *workspace, size_t workspace_bytes, int B, int T,
+                                         int T_ref, gtts_stream_t stream) {
+    int rc = vc_check(plan, B, T, T_ref);
+    if (rc) return rc;
+    if (!packed || !x || !x_mask || !mean || !c || !t || !out || !workspace) return fail(GTTS_E_NULL, "gtts_vc_estimator_forward: null argument");
+    gtts_plan *p = const_cast<gtts_plan *>(plan);
+    if (p->cfg.use_ref_t && (!xt_ref || !ref_mask)) return fail(GTTS_E_NULL, "use_ref_t plan needs xt_ref and ref_mask");
+    layout_workspace(p, B, T, std::max(B, 4096), T_ref);
+    if (workspace_bytes < p->ws_bytes) return fail(GTTS_E_WORKSPACE, "workspace too small: need %zu bytes, got %zu", p->ws_bytes, workspace_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned char *blob = (const unsigned char *)packed;
+    RunCtx cx{p, blob, (unsigned char *)workspace, x_mask, B, T, nullptr, 0, st};
+    cx.ref_mask = ref_mask; cx.Tr = T_ref; cx.in_x = x; cx.in_mean = mean; cx.in_c = c;
+    const int F = p->cfg.n_feats;
+    float *tb = tptr(cx, p->t_tb);
+    { ProfScope ps_(p, st, (int)p->ops.size() + XOP_TIME); HIPCHK(launch_time_mlp(t, (const float *)(blob + p->freq_off), p->cfg.pe_scale, blob, p->tmlp, tb, B, st)); }
+    cx.tb_row = tb;
+    cx.tb_bstride = p->tmlp.tb_stride;
+    if (p->cfg.use_ref_t)
+        HIPCHK(hipMemcpyAsync(tptr(cx, p->t_xtref), xt_ref, (size_t)B * F * T_ref * sizeof(float), hipMemcpyDeviceToDevice, st));
+    rc = run_ops(cx);
+    if (rc) return rc;
+    { ProfScope ps_(p, st, (int)p->ops.size() + XOP_FINAL); HIPCHK(launch_final_euler(tptr(cx, p->t_final_raw), tptr(cx, p->t_final_sc), tptr(cx, p->t_final_sh),
+                              (const float *)(blob + p->fw_off), (const float *)(blob + p->fb_off), x_mask, B, p->cfg.dim, F, T,
+                              out, nullptr, nullptr, nullptr, 0.f, 0.f, st)); }
+    return GTTS_OK;
+}
+
+// host scalars of the DiffVC schedule (DiffVC/model/diffusion.py:120-149), Python-double arithmetic
+static double vc_gamma(const gtts_unet_cfg &cf, double s, double t, double pw = 1.0) {
+    double bi = cf.vc_beta_min + 0.5 * (cf.vc_beta_max - cf.vc_beta_min) * (t + s);
+    bi *= (t - s);
+    return exp(-0.5 * pw * bi);
+}
+
+extern "C" int gtts_vc_reverse_diffusion(const gtts_plan *plan, const void *packed, const float *z, const float *mask,
+                                         const float *mean, const float *ref, const float *ref_mask, const float *mean_ref,
+                                         const float *c, const float *noise, float *out, void *workspace,
+                                         size_t workspace_bytes, int B, int T, int T_ref, int n_timesteps, int mode,
+                                         gtts_stream_t stream) {
+    int rc = vc_check(plan, B, T, T_ref);
+    if (rc) return rc;
+    if (!packed || !z || !mask || !mean || !c || !out || !workspace) return fail(GTTS_E_NULL, "gtts_vc_reverse_diffusion: null argument");
+    if (n_timesteps <= 0 || n_timesteps > 4096) return fail(GTTS_E_SHAPE, "n_timesteps must be in [1, 4096], got %d", n_timesteps);
+    if (mode < 0 || mode > 2) return fail(GTTS_E_CONFIG, "mode must be 0 ('pf'), 1 ('em') or 2 ('ml')");
+    if (mode != 0 && !noise) return fail(GTTS_E_NULL, "'em' / 'ml' sampling needs the pre-drawn noise tensor");
+    gtts_plan *p = const_cast<gtts_plan *>(plan);
+    const gtts_unet_cfg &cf = p->cfg;
+    if (cf.use_ref_t && (!ref || !ref_mask || !mean_ref)) return fail(GTTS_E_NULL, "use_ref_t plan needs ref, ref_mask and mean_ref");
+    layout_workspace(p, B, T, std::max(B, 4096), T_ref);
+    if (workspace_bytes < p->ws_bytes) return fail(GTTS_E_WORKSPACE, "workspace too small: need %zu bytes, got %zu", p->ws_bytes, workspace_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned char *blob = (const unsigned char *)packed;
+    RunCtx cx{p, blob, (unsigned char *)workspace, mask, B, T, nullptr, 0, st};
+    cx.ref_mask = ref_mask; cx.Tr = T_ref; cx.in_mean = mean; cx.in_c = c; cx.in_x = out;
+    const int F = cf.n_feats, N = n_timesteps;
+    // step times t_i = 1 - i*h (left endpoint, diffusion.py:170) -> fp32 `time` tensor values, all rows in one launch
+    float *tb = tptr(cx, p->t_tb);
+    float *tvals = tb + (size_t)std::max(B, 4096) * p->tmlp.tb_stride;
+    std::vector<float> th(N);
+    const double hd = 1.0 / (double)N;
+    for (int i = 0; i < N; ++i) th[i] = (float)(1.0 - (double)i * hd);
+    HIPCHK(hipMemcpyAsync(tvals, th.data(), (size_t)N * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));      // th is a host temporary
+    { ProfScope ps_(p, st, (int)p->ops.size() + XOP_TIME); HIPCHK(launch_time_mlp(tvals, (const float *)(blob + p->freq_off), cf.pe_scale, blob, p->tmlp, tb, N, st)); }
+    { ProfScope ps_(p, st, (int)p->ops.size() + XOP_MULMASK); HIPCHK(launch_mul_mask(z, mask, out, B, F, T, st)); }
+    for (int i = 0; i < N; ++i) {
+        const double t = 1.0 - (double)i * hd;
+        const double beta_t = cf.vc_beta_min + (cf.vc_beta_max - cf.vc_beta_min) * t;
+        double kappa = 0.0, omega = 0.0, sigma = 0.0;
+        if (mode == 2) {
+            kappa = vc_gamma(cf, 0, t - hd) * (1.0 - vc_gamma(cf, t - hd, t, 2.0));
+            kappa /= (vc_gamma(cf, 0, t) * beta_t * hd);
+            kappa -= 1.0;
+            const double cden = 1.0 - vc_gamma(cf, 0, t, 2.0);
+            const double nu = vc_gamma(cf, 0, t - hd) * (1.0 - vc_gamma(cf, t - hd, t, 2.0)) / cden;
+            const double mu = vc_gamma(cf, t - hd, t) * (1.0 - vc_gamma(cf, 0, t - hd, 2.0)) / cden;
+            omega = nu / vc_gamma(cf, 0, t);
+            omega += mu;
+            omega -= (0.5 * beta_t * hd + 1.0);
+            sigma = sqrt((1.0 - vc_gamma(cf, 0, t - hd, 2.0)) * (1.0 - vc_gamma(cf, t - hd, t, 2.0)) / cden);
+        } else if (mode == 1) {
+            sigma = sqrt(beta_t * hd);
+        }
+        VcStep vs;
+        vs.mode = mode == 0 ? 1 : 2;
+        vs.cm = (float)(0.5 * beta_t * hd + omega);
+        vs.k1 = (float)(1.0 + kappa);
+        vs.bh = (float)(beta_t * hd);
+        vs.sigma = (float)sigma;
+        if (cf.use_ref_t) {
+            const double g0 = vc_gamma(cf, 0, t);
+            HIPCHK(launch_xt_ref(ref, mean_ref, ref_mask, tptr(cx, p->t_xtref), (float)g0, (float)(1.0 - g0), B, F, T_ref, st));
+        }
+        cx.tb_row = tb + (size_t)i * p->tmlp.tb_stride;
+        cx.tb_bstride = 0;
+        rc = run_ops(cx);
+        if (rc) return rc;
+        const float *nz = (mode != 0) ? noise + (size_t)i * B * F * T : nullptr;
+        { ProfScope ps_(p, st, (int)p->ops.size() + XOP_FINAL); HIPCHK(launch_final_euler(tptr(cx, p->t_final_raw), tptr(cx, p->t_final_sc), tptr(cx, p->t_final_sh),
+                                  (const float *)(blob + p->fw_off), (const float *)(blob + p->fb_off), mask, B, cf.dim, F, T,
+                                  nullptr, out, mean, nz, 0.f, 0.f, st, &vs)); }
+    }
+    return GTTS_OK;
+}
+
 extern "C" size_t gtts_mas_scratch_bytes(int b, int tx, int ty) {
     if (b <= 0 || tx <= 0 || ty <= 0) return 0;
     return (size_t)b * tx * ty;
@@ -914,6 +1164,10 @@ extern "C" int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, con
             case OP_ACTX: s_kernel = plan->cfg.precision == GTTS_PREC_BF16 ? "gtts::attn_ctx_kernel<1>" : "gtts::attn_ctx_kernel<2>"; fl = 2.0 * B * Hi * Wi * (256.0 * o.C + 128.0 * 32);
                 by = 4.0 * B * o.C * Hi * Wi; break;
             case OP_AMERGE: s_kernel = "gtts::attn_merge_kernel"; break;
+            case OP_INSTATS: s_kernel = "gtts::instnorm_stats_kernel"; by = 4.0 * B * o.C * Hi * Wi; break;
+            case OP_REFPOOL: s_kernel = "gtts::ref_pool_kernel"; by = 8.0 * B * o.C * Hi * Wi; break;
+            case OP_VCCOND: s_kernel = "gtts::vc_cond_kernel"; break;
+            case OP_PREPVC: s_kernel = "gtts::prep_vc_kernel"; by = 4.0 * B * plan->cin0 * Hi * Wi; break;
             case OP_AFOLD: s_kernel = "gtts::attn_fold_kernel"; fl = 2.0 * B * (o.C * 128.0 * 32 + (double)o.C * o.C * 128); break;
         }
     }
