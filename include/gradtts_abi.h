@@ -138,6 +138,9 @@ int gtts_plan_num_tensors(const gtts_plan *plan);
 /* offset is in bytes into the workspace for the given (B,T); dims = {B,C,H,W}. */
 int gtts_plan_tensor_info(const gtts_plan *plan, int i, int B, int T, const char **name, size_t *offset,
                           int dims[4]);
+/* same for DiffVC plans, whose RefBlock tensors live on the reference mel's frame axis (T_ref) */
+int gtts_vc_tensor_info(const gtts_plan *plan, int i, int B, int T, int T_ref, const char **name, size_t *offset,
+                        int dims[4]);
 
 /* ---- measurement: per-op HIP-event timing of the op program (bench.py roofline) ------------------------- */
 /* Ops are the kernel launches of one estimator call, in launch order; label = layer name, kernel = the HIP kernel

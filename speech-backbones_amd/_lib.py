@@ -67,6 +67,8 @@ def lib():
         L.gtts_vc_workspace_bytes.restype = sz
         L.gtts_vc_estimator_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, i, vp]
         L.gtts_vc_reverse_diffusion.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, i, i, i, vp]
+        L.gtts_vc_tensor_info.argtypes = [vp, i, i, i, i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz),
+                                          ctypes.POINTER(i * 4)]
         L.gtts_plan_num_ops.argtypes = [vp]
         L.gtts_plan_op_info.argtypes = [vp, i, i, i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p),
                                         ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
@@ -269,8 +271,8 @@ class Plan:
         out = {}
         for k in range(L.gtts_plan_num_tensors(self._h)):
             name, off, dims = ctypes.c_char_p(), ctypes.c_size_t(), (ctypes.c_int * 4)()
-            _check(L.gtts_plan_tensor_info(self._h, k, int(B), int(T), ctypes.byref(name), ctypes.byref(off),
-                                           ctypes.byref(dims)), "gtts_plan_tensor_info")
+            _check(L.gtts_vc_tensor_info(self._h, k, int(B), int(T), int(Tr), ctypes.byref(name), ctypes.byref(off),
+                                         ctypes.byref(dims)), "gtts_vc_tensor_info")
             out[name.value.decode()] = (off.value, tuple(dims))
         return ws, out
 

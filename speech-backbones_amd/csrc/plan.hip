@@ -658,17 +658,24 @@ extern "C" size_t gtts_workspace_bytes(const gtts_plan *plan, int B, int T) {
 
 extern "C" int gtts_plan_num_tensors(const gtts_plan *plan) { return plan ? (int)plan->tensors.size() : 0; }
 
+extern "C" int gtts_vc_tensor_info(const gtts_plan *plan, int i, int B, int T, int T_ref, const char **name, size_t *offset,
+                                   int dims[4]);
 extern "C" int gtts_plan_tensor_info(const gtts_plan *plan, int i, int B, int T, const char **name, size_t *offset,
                                      int dims[4]) {
+    return gtts_vc_tensor_info(plan, i, B, T, T, name, offset, dims);
+}
+
+extern "C" int gtts_vc_tensor_info(const gtts_plan *plan, int i, int B, int T, int T_ref, const char **name, size_t *offset,
+                                   int dims[4]) {
     if (check_shape(plan, B, T) != GTTS_OK) return GTTS_E_SHAPE;
     if (i < 0 || i >= (int)plan->tensors.size()) return fail(GTTS_E_SHAPE, "tensor index out of range");
     gtts_plan *p = const_cast<gtts_plan *>(plan);
-    layout_workspace(p, B, T, std::max(B, 4096));
+    layout_workspace(p, B, T, std::max(B, 4096), T_ref);
     const Tensor &t = p->tensors[i];
     if (name) *name = t.name.c_str();
     if (offset) *offset = p->offsets[i];
     if (dims) {
-        dims[0] = B; dims[1] = t.C; dims[2] = p->cfg.n_feats >> t.lvl; dims[3] = T >> t.lvl;
+        dims[0] = B; dims[1] = t.C; dims[2] = p->cfg.n_feats >> t.lvl; dims[3] = (t.tref ? T_ref : T) >> t.lvl;
         if (t.kind != TK_ACT) { dims[2] = 1; dims[3] = 1; }
         if (t.kind == TK_ROWS) { dims[0] = B; dims[1] = p->tmlp.tb_stride; }   // first B rows (estimator call)
     }
