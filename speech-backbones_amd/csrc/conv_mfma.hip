@@ -58,7 +58,11 @@ static inline size_t conv_smem_bytes(int npix, int nkg, int wblk16, int cin, int
            (size_t)3 * mt * 4;
 }
 
-template <int MODE, int WM, int WN, int MF, int KCH, int PRO, int EPI, int NSPLIT>
+// FULLC = 1: cin is a multiple of 16 (and a concatenated input splits on a 16-channel boundary), so there is no
+// channel padding and every chunk comes from one source.  Then all global loads are buffer loads -- per-lane byte
+// offset fixed per staging item, per-chunk/channel offset in an SGPR -- and need no VALU address arithmetic, and the
+// zero padding of the halo is produced by the mask factor alone (out-of-image items read offset 0 and get m = 0).
+template <int MODE, int WM, int WN, int MF, int KCH, int PRO, int EPI, int NSPLIT, int FULLC>
 __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void conv_mfma_kernel(const ConvArgs a) {
     using C = ConvCfg<MODE, WM, WN, MF, KCH>;
     constexpr int MT = C::MT, TR = C::TR, TC = C::TC, NST = C::NST, TPS = C::TPS, NKG = C::NKG;
@@ -120,7 +124,8 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
 
     // ---- staging items: geometry is chunk-invariant.  Out-of-image items load from offset 0 (valid memory)
     // and are zeroed by a select.
-    int it_goff[AITER];     // offset inside a channel plane (clamped to 0 when outside the image)
+    int it_goff[AITER];     // offset inside a channel plane (clamped to 0 when outside the image); FULLC: byte offset
+                            // of (first channel of the item's 8-group, pixel) inside the chunk
     float it_m[AITER];      // mask value at the item's frame; < 0 encodes "outside the image / no item"
 #pragma unroll
     for (int it = 0; it < AITER; ++it) {
@@ -132,6 +137,7 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
         const int gy = iy0 + pr, gx = ix0 + pc;
         const bool in = has && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
         it_goff[it] = in ? gy * a.Win + gx : 0;
+        if (FULLC) it_goff[it] = (it_goff[it] + min(kg, NKG - 1) * 8 * HWin) * 4;
         float m = 1.f;
         if (PRO != PRO_PLAIN) m = a.mask[(size_t)b * a.T + ((size_t)(in ? gx : 0) << a.lvl_in)];
         it_m[it] = in ? m : -1.f;
@@ -139,7 +145,37 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
 
     float araw[AITER][8];
     float brawst[PRO == PRO_IGLU ? AITER : 1][8];      // PRO_IGLU: the gate half (channel c + cin)
+    // buffer descriptors (FULLC): built per chunk from wave-uniform scalars (readfirstlane keeps them in SGPRs --
+    // a descriptor the compiler believes divergent is loaded through a waterfall loop)
+    const int srcC0 = PRO == PRO_IGLU ? 2 * a.cin : a.c0;
+    const float *sbase0 = a.src0 + (size_t)b * srcC0 * HWin;
+    const float *sbase1 = a.c1 > 0 ? a.src1 + (size_t)b * a.c1 * HWin : sbase0;
+    auto uniform_rsrc = [](const void *p, int bytes) {
+        const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0,
+                                                 __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+    };
     auto load_act = [&](int chunk) {
+        if constexpr (FULLC) {
+            const int cb = chunk * (8 * NKG);
+            const bool first = cb < a.c0 || PRO == PRO_IGLU;
+            const __amdgpu_buffer_rsrc_t rs0 =
+                uniform_rsrc(first ? sbase0 : sbase1, (first ? srcC0 : a.c1) * HWin * 4);
+            const int soff = (first ? cb : cb - a.c0) * HWin * 4;
+#pragma unroll
+            for (int it = 0; it < AITER; ++it) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int so = soff + i * HWin * 4;
+                    araw[it][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs0, it_goff[it], so, 0));
+                    if (PRO == PRO_IGLU)
+                        brawst[it][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs0, it_goff[it], so + a.cin * HWin * 4, 0));
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < AITER; ++it) {
             const int idx = tid + it * 256;
@@ -163,11 +199,13 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
 
     const unsigned char *wbase = a.w + (size_t)b * a.w_bstride;
     u32x4 wregs[WITER];
+    const int wtotal = (MODE == CONV_UP ? 4 : 1) * a.nchunk * NST * ncot * WBLK16 * 16;       // bytes of this conv's blocks
+    const __amdgpu_buffer_rsrc_t rsw = uniform_rsrc(wbase, wtotal);
     auto load_w = [&](int chunk, int stage) {
-        size_t blk = (((size_t)phase * a.nchunk + chunk) * NST + stage) * ncot + cot;
-        const u32x4 *g = reinterpret_cast<const u32x4 *>(wbase + blk * (size_t)(WBLK16 * 16));
+        const int blk = ((phase * a.nchunk + chunk) * NST + stage) * ncot + cot;
 #pragma unroll
-        for (int i = 0; i < WITER; ++i) wregs[i] = g[tid + i * 256];
+        for (int i = 0; i < WITER; ++i)
+            wregs[i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (tid + i * 256) * 16, blk * (WBLK16 * 16), 0);
     };
 
     f32x16 acc[MF][2];
@@ -226,7 +264,8 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
             bf16x8 vh, vl;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                float v = (inb && i < nval) ? araw[it][i] : 0.f;
+                float v = araw[it][i];
+                if (!FULLC) v = (inb && i < nval) ? v : 0.f;     // FULLC: zeroing comes from m == 0 (see kernel comment)
                 if (PRO == PRO_MASK) {
                     v *= m;
                 } else if (PRO == PRO_GN) {
@@ -236,7 +275,8 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
                     const float ga = v * sc[i] + sh[i];
                     const float gb = brawst[it][i] * scb[i] + shb[i];
                     const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-gb));     // sigmoid
-                    v = (inb && i < nval) ? (ga * sg + tb[i]) * m : 0.f;
+                    v = (ga * sg + tb[i]) * m;
+                    if (!FULLC) v = (inb && i < nval) ? v : 0.f;
                 }
                 __bf16 h, l;
                 split_bf16(v, h, l);
@@ -750,7 +790,7 @@ static inline bool conv_pipe_enabled() {
     return v == 1;
 }
 
-template <int MODE, int WM, int WN, int MF, int KCH, int PRO, int EPI, int NSPLIT>
+template <int MODE, int WM, int WN, int MF, int KCH, int PRO, int EPI, int NSPLIT, int FULLC>
 static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
     using C = ConvCfg<MODE, WM, WN, MF, KCH>;
     ConvArgs a = a_in;
@@ -766,7 +806,7 @@ static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
     static size_t attr_set = 0;
     if (smem > attr_set) {
         hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&conv_mfma_kernel<MODE, WM, WN, MF, KCH, PRO, EPI, NSPLIT>),
+            reinterpret_cast<const void *>(&conv_mfma_kernel<MODE, WM, WN, MF, KCH, PRO, EPI, NSPLIT, FULLC>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr_set = smem;
@@ -784,7 +824,7 @@ static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
         hipLaunchKernelGGL((conv_pipe_kernel<MODE, WM, WN, MF, KCH, PRO, EPI, NSPLIT>), grid, dim3(256), smem2, st, a);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, MF, KCH, PRO, EPI, NSPLIT>), grid, dim3(256), smem, st, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, MF, KCH, PRO, EPI, NSPLIT, FULLC>), grid, dim3(256), smem, st, a);
     return hipGetLastError();
 }
 
@@ -799,8 +839,16 @@ int conv_nparts(int mode, int cout, int Hout, int Wout) {
 //   C3: (MASK | GN, STATS)   DN, UP: (MASK, PLAIN)   P1: (MASK, TAIL) | (PLAIN, ATTN)
 template <int MODE, int WM, int WN, int MF, int PRO, int EPI>
 static hipError_t launch_prec(const ConvArgs &a, hipStream_t st) {
-    return a.nsplit > 1 ? launch_cfg<MODE, WM, WN, MF, 1, PRO, EPI, 2>(a, st)
-                        : launch_cfg<MODE, WM, WN, MF, 1, PRO, EPI, 1>(a, st);
+    const bool fullc = a.cin % 16 == 0 && (a.c1 == 0 || a.c0 % 16 == 0);
+    // ragged channel counts only occur on first layers (stacked input, 1-channel reference): PRO_MASK variants
+    constexpr bool ragged_ok = PRO == PRO_MASK && (MODE == CONV_C3 || MODE == CONV_P1);
+    if (fullc)
+        return a.nsplit > 1 ? launch_cfg<MODE, WM, WN, MF, 1, PRO, EPI, 2, 1>(a, st)
+                            : launch_cfg<MODE, WM, WN, MF, 1, PRO, EPI, 1, 1>(a, st);
+    if constexpr (ragged_ok)
+        return a.nsplit > 1 ? launch_cfg<MODE, WM, WN, MF, 1, PRO, EPI, 2, 0>(a, st)
+                            : launch_cfg<MODE, WM, WN, MF, 1, PRO, EPI, 1, 0>(a, st);
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_conv(int mode, const ConvArgs &a, hipStream_t st) {

@@ -1127,7 +1127,7 @@ static std::string conv_kernel_name(int mode, int cin, int cout, int pro, int ep
     else if (wide) { wm = 2; wn = 2; mf = 2; }
     else { wm = 1; wn = 4; mf = 2; }
     char buf[96];
-    snprintf(buf, sizeof buf, "gtts::conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", mode, wm, wn, mf, kch, pro, epi, nsplit);
+    snprintf(buf, sizeof buf, "gtts::conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d>", mode, wm, wn, mf, kch, pro, epi, nsplit, cin % 16 == 0 ? 1 : 0);
     return buf;
 }
 
