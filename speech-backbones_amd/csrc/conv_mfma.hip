@@ -31,6 +31,12 @@
 #define GTTS_C3_WAVES 3
 #endif
 #define GTTS_WAVES(MODE) ((MODE) == CONV_DN ? 2 : GTTS_C3_WAVES)
+// GTTS_EXP: timing-only ablations of the main loop (results are WRONG; never set in a product build)
+//   1 no MFMAs   2 no fragment ds_reads   3 no activation transform/ds_write   4 no weight staging   5 no barriers
+#ifndef GTTS_EXP
+#define GTTS_EXP 0
+#endif
+#define GTTS_SYNC() do { if (GTTS_EXP != 5) __syncthreads(); } while (0)
 
 namespace gtts {
 
@@ -222,10 +228,10 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
     const int m0 = wm * MF * 32;
 
     for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-        __syncthreads();   // previous chunk's MFMAs are done with s_a* / s_w (and s_par is written)
+        GTTS_SYNC();   // previous chunk's MFMAs are done with s_a* / s_w (and s_par is written)
         // ---- transform + split + stage the activation tile of this chunk (straight-line code)
 #pragma unroll
-        for (int it = 0; it < AITER; ++it) {
+        for (int it = 0; it < (GTTS_EXP == 3 ? 0 : AITER); ++it) {
             const int idx = tid + it * 256;
             const int kg = min(idx / NPIX, NKG - 1);
             const int p = idx - (idx / NPIX) * NPIX;
@@ -291,13 +297,14 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
         }
 #pragma unroll
         for (int stage = 0; stage < NST; ++stage) {
-            if (stage > 0) __syncthreads();   // previous stage's MFMAs are done with s_w
+            if (stage > 0) GTTS_SYNC();   // previous stage's MFMAs are done with s_w
 #pragma unroll
-            for (int i = 0; i < WITER; ++i) s_w[tid + i * 256] = wregs[i];
-            __syncthreads();
+            for (int i = 0; i < (GTTS_EXP == 4 ? 0 : WITER); ++i) s_w[tid + i * 256] = wregs[i];
+            GTTS_SYNC();
             // ---- prefetch behind the MFMAs: next weight block (one stage ahead) and, as early as the staging
             // registers are free again, the next activation chunk (a whole chunk of MFMAs ahead)
-            if (stage + 1 < NST) load_w(chunk, stage + 1);
+            if (GTTS_EXP == 4) {
+            } else if (stage + 1 < NST) load_w(chunk, stage + 1);
             else if (chunk + 1 < a.nchunk) load_w(chunk + 1, 0);
             if (stage == 0 && chunk + 1 < a.nchunk) load_act(chunk + 1);
 
@@ -318,6 +325,10 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
 #pragma unroll
                 for (int kc = 0; kc < KCH; ++kc) {
                     bf16x8 wh[MF], wl[MF], xh[2], xl[2];
+#if GTTS_EXP == 2
+                    for (int mi = 0; mi < MF; ++mi) { wh[mi] = __builtin_bit_cast(bf16x8, wregs[0]); wl[mi] = wh[mi]; }
+                    for (int ni = 0; ni < 2; ++ni) { xh[ni] = __builtin_bit_cast(bf16x8, wregs[1]); xl[ni] = xh[ni]; }
+#else
 #pragma unroll
                     for (int mi = 0; mi < MF; ++mi) {
                         int wi = (j * NKG + kc * 2 + kg_l) * MT + m0 + mi * 32 + l31;
@@ -330,6 +341,18 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
                         xh[ni] = *reinterpret_cast<const bf16x8 *>(&s_ah[xi]);
                         if (NSPLIT > 1) xl[ni] = *reinterpret_cast<const bf16x8 *>(&s_al[xi]);
                     }
+#endif
+#if GTTS_EXP == 1
+#pragma unroll
+                    for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {      // consume the fragments with a handful of VALU ops
+                            const u32x4 p = __builtin_bit_cast(u32x4, wh[mi]) ^ __builtin_bit_cast(u32x4, xh[ni]);
+                            u32x4 q = p;
+                            if (NSPLIT > 1) q = __builtin_bit_cast(u32x4, wl[mi]) ^ __builtin_bit_cast(u32x4, xl[ni]);
+                            acc[mi][ni][0] += __builtin_bit_cast(float, (p[0] ^ p[1] ^ p[2] ^ p[3] ^ q[0] ^ q[1] ^ q[2] ^ q[3]) & 0x3fffffffu);
+                        }
+#else
 #pragma unroll
                     for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
@@ -340,6 +363,7 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
                             }
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[mi], xh[ni], acc[mi][ni], 0, 0, 0);
                         }
+#endif
                 }
             }
         }

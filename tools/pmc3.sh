@@ -1,0 +1,12 @@
+#!/bin/bash
+# kernel-trace stats + SQ busy/stall + LDS activity + instruction mix, single stream (clean per-kernel counters)
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp GTTS_STREAMS=1
+TAG=${1:-x}; ROOT=$PWD; cd /tmp
+pass() { name=$1; shift; timeout 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmc_$name -o p -- python $ROOT/bench.py --steps 1 --warmup 0 --timesteps 2 --no-cpu-baseline --no-roofline > /tmp/pmc_$name.log 2>&1; echo "pass $name rc=$?"; f=$(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1); python $ROOT/tools/pmc_summarize.py "$f" > $ROOT/gpurun_out/pmc_${name}_$TAG.txt 2>&1; }
+pass sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT
+pass active SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_LDS_IDX_ACTIVE SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES
+pass insts SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_WAVE_CYCLES
+for n in sq active insts; do echo "== $n"; head -8 $ROOT/gpurun_out/pmc_${n}_$TAG.txt | cut -c1-260; done
+cd /tmp && GTTS_STREAMS=2 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o prof -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/prof_$TAG.log 2>&1
+for f in $(find /tmp/prof_$TAG -name "*kernel_stats*.csv"); do cp $f $ROOT/gpurun_out/rocprof_kernel_stats_$TAG.csv; done
+head -22 $ROOT/gpurun_out/rocprof_kernel_stats_$TAG.csv | cut -c1-200
