@@ -191,16 +191,42 @@ __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
             }
     }
 
-    // ---- per-wave partial record: m[32], Z[32], ctx[32][32] (relative to m)
-    float *rec = a.partials + ((((size_t)b * 4 + head) * a.nrec) + (size_t)slice * 4 + wave) * ATTN_REC;
-    if (kgl == 0) {
-        rec[l31] = m_run;
-        rec[32 + l31] = z_run;
-    }
+    // ---- merge the four waves' partials (log-sum-exp, fixed order) -> one record per workgroup:
+    // m[32], Z[32], ctx[32][32] (relative to m)
+    __shared__ float s_mrg[4][ATTN_REC];
+    {
+        float *mine = s_mrg[wave];
+        if (kgl == 0) {
+            mine[l31] = m_run;
+            mine[32 + l31] = z_run;
+        }
 #pragma unroll
-    for (int rg = 0; rg < 16; ++rg) {
-        const int d = (rg & 3) + 8 * (rg >> 2) + 4 * kgl;
-        rec[64 + d * 32 + l31] = ctx[rg];
+        for (int rg = 0; rg < 16; ++rg) {
+            const int d = (rg & 3) + 8 * (rg >> 2) + 4 * kgl;
+            mine[64 + d * 32 + l31] = ctx[rg];
+        }
+    }
+    __syncthreads();
+    float *rec = a.partials + ((((size_t)b * 4 + head) * a.nrec) + (size_t)slice) * ATTN_REC;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = tid + 256 * k, d = idx >> 5;
+        float M = NEG_INF;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) M = fmaxf(M, s_mrg[w][d]);
+        float acc_c = 0.f, acc_z = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float mw = s_mrg[w][d];
+            const float sc = (mw == NEG_INF) ? 0.f : __expf(mw - M);
+            acc_c = fmaf(s_mrg[w][64 + idx], sc, acc_c);
+            acc_z = fmaf(s_mrg[w][32 + d], sc, acc_z);
+        }
+        rec[64 + idx] = acc_c;
+        if ((idx & 31) == 0) {
+            rec[d] = M;
+            rec[32 + d] = acc_z;
+        }
     }
 }
 
@@ -286,50 +312,91 @@ hipError_t launch_attn_merge(const float *partials, float *ctxn, int B, int nrec
 }
 
 // ------------------------------------------------------------------------------------------------ attn_fold
-// grid (C/16, B).  M[co][ci] = g * sum_{h,d} U[co][h,d] Wq[h*32+d][ci],  U[co][h,d] = sum_e Wout[co][h*32+e] ctx_h[d][e]
-__global__ void attn_fold_kernel(const float *__restrict__ ctxn, const float *__restrict__ wq,
-                                 const float *__restrict__ wout, const float *__restrict__ bout,
-                                 const float *__restrict__ g, unsigned char *__restrict__ wpk, size_t wpk_bstride,
-                                 float *__restrict__ biasb, int C, int MT, int nkg) {
-    __shared__ float s_U[16][128];
-    const int co0 = blockIdx.x * 16, b = blockIdx.y, tid = threadIdx.x;
+// M[co][ci] = g * sum_{h,d} U[co][h,d] Wq[h*32+d][ci],  U[co][h,d] = sum_e Wout[co][h*32+e] ctx_h[d][e]
+// grid (C/8, B), 256 threads: a workgroup owns 8 output channels of one sample.  The 128-long (h,d) contraction is
+// split over 256 / min(C,256) thread groups (short dependent chains, many loads in flight -- the kernel is pure
+// latency) and combined through LDS in a fixed order.
+constexpr int FOLD_CO = 8;
+__global__ __launch_bounds__(256) void attn_fold_kernel(const float *__restrict__ ctxn, const float *__restrict__ wq,
+                                                         const float *__restrict__ wout, const float *__restrict__ bout,
+                                                         const float *__restrict__ g, unsigned char *__restrict__ wpk,
+                                                         size_t wpk_bstride, float *__restrict__ biasb, int C, int MT,
+                                                         int nkg) {
+    __shared__ float s_U[FOLD_CO][128];
+    __shared__ float s_part[4][FOLD_CO][128];     // partial sums of j-groups 1..3 (only used when C <= 128)
+    const int co0 = blockIdx.x * FOLD_CO, b = blockIdx.y, tid = threadIdx.x;
     const float *cb = ctxn + (size_t)b * 4096;
-    for (int idx = tid; idx < 16 * 128; idx += 256) {
-        const int r = idx >> 7, j = idx & 127, h = j >> 5, d = j & 31;
-        const float *wo = wout + (size_t)(co0 + r) * 128 + h * 32;
-        const float *cx = cb + (h * 32 + d) * 32;
-        float acc = 0.f;
-#pragma unroll 8
-        for (int e = 0; e < 32; ++e) acc = fmaf(wo[e], cx[e], acc);
-        s_U[r][j] = acc;
+    {   // U: 8 x 128 outputs, 4 per thread, 32-long dot products of contiguous rows
+        const int j = tid & 127, h = j >> 5, d = j & 31;
+        const float4 *cx = reinterpret_cast<const float4 *>(cb + (h * 32 + d) * 32);
+        float4 cv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cv[e] = cx[e];
+#pragma unroll
+        for (int rr = 0; rr < FOLD_CO / 2; ++rr) {
+            const int r = (tid >> 7) * (FOLD_CO / 2) + rr;
+            const float4 *wo = reinterpret_cast<const float4 *>(wout + (size_t)(co0 + r) * 128 + h * 32);
+            float acc = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float4 w4 = wo[e];
+                acc = fmaf(w4.x, cv[e].x, acc); acc = fmaf(w4.y, cv[e].y, acc);
+                acc = fmaf(w4.z, cv[e].z, acc); acc = fmaf(w4.w, cv[e].w, acc);
+            }
+            s_U[r][j] = acc;
+        }
     }
     __syncthreads();
     const float gv = g[0];
     const int ncot = (C + MT - 1) / MT;
     __bf16 *wp = reinterpret_cast<__bf16 *>(wpk + (size_t)b * wpk_bstride);
-    for (int ci = tid; ci < C; ci += 256) {
-        float acc[16];
+    const int Cc = C < 256 ? C : 256;          // input channels handled per pass
+    const int nj = 256 / Cc >= 4 ? 4 : (256 / Cc >= 2 ? 2 : 1);   // j-groups (C = 64: 4, 128: 2, >= 256: 1)
+    const int jq = tid / Cc, cl = tid - jq * Cc;
+    const int jn = 128 / nj;                   // contraction length per group
+    const bool active = jq < nj;               // C not dividing 256 leaves a few threads idle
+    for (int ci = cl; ci < C; ci += Cc) {
+        float acc[FOLD_CO];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        for (int j = 0; j < 128; ++j) {
-            const float q = wq[(size_t)j * C + ci];
+        for (int r = 0; r < FOLD_CO; ++r) acc[r] = 0.f;
+        const float *qp = wq + (size_t)(active ? jq * jn : 0) * C + ci;
+        for (int j0 = 0; j0 < (active ? jn : 0); j0 += 8) {
+            float q[8];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = fmaf(s_U[r][j], q, acc[r]);
+            for (int u = 0; u < 8; ++u) q[u] = qp[(size_t)(j0 + u) * C];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int r = 0; r < FOLD_CO; ++r) acc[r] = fmaf(s_U[r][jq * jn + j0 + u], q[u], acc[r]);
         }
-        const int chunk = ci / (8 * nkg), kg = (ci >> 3) % nkg, i = ci & 7;
+        if (nj > 1) {
+            if (active && jq > 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + r, cot = co / MT, m = co % MT;
-            const size_t blk = (size_t)chunk * ncot + cot;             // CONV_P1: one stage, one tap
-            const size_t e_hi = blk * ((size_t)MT * 16 * nkg) + ((size_t)(0 * nkg + kg) * MT + m) * 8 + i;
-            const size_t e_lo = blk * ((size_t)MT * 16 * nkg) + ((size_t)(1 * nkg + kg) * MT + m) * 8 + i;
-            __bf16 hi, lo;
-            split_bf16(acc[r] * gv, hi, lo);
-            wp[e_hi] = hi;
-            wp[e_lo] = lo;
+                for (int r = 0; r < FOLD_CO; ++r) s_part[jq][r][cl] = acc[r];
+            }
+            __syncthreads();                   // uniform: nj > 1 implies a single pass of the ci loop
+            if (jq == 0) {
+                for (int k = 1; k < nj; ++k)
+#pragma unroll
+                    for (int r = 0; r < FOLD_CO; ++r) acc[r] += s_part[k][r][cl];
+            }
+        }
+        if (jq == 0) {
+            const int chunk = ci / (8 * nkg), kg = (ci >> 3) % nkg, i = ci & 7;
+#pragma unroll
+            for (int r = 0; r < FOLD_CO; ++r) {
+                const int co = co0 + r, cot = co / MT, m = co % MT;
+                const size_t blk = (size_t)chunk * ncot + cot;             // CONV_P1: one stage, one tap
+                const size_t e_hi = blk * ((size_t)MT * 16 * nkg) + ((size_t)(0 * nkg + kg) * MT + m) * 8 + i;
+                const size_t e_lo = blk * ((size_t)MT * 16 * nkg) + ((size_t)(1 * nkg + kg) * MT + m) * 8 + i;
+                __bf16 hi, lo;
+                split_bf16(acc[r] * gv, hi, lo);
+                wp[e_hi] = hi;
+                wp[e_lo] = lo;
+            }
         }
     }
-    if (tid < 16) biasb[(size_t)b * C + co0 + tid] = gv * bout[co0 + tid];
+    if (tid < FOLD_CO) biasb[(size_t)b * C + co0 + tid] = gv * bout[co0 + tid];
 }
 
 hipError_t launch_attn_fold(const float *ctxn, const float *wq, const float *wout, const float *bout, const float *g,
@@ -337,8 +404,8 @@ hipError_t launch_attn_fold(const float *ctxn, const float *wq, const float *wou
     if (C % 16 != 0) return hipErrorInvalidValue;
     ConvGeom geom = conv_geom(CONV_P1, C, C);
     if (C % (16 * geom.kch) != 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(attn_fold_kernel, dim3(C / 16, B), dim3(256), 0, st, ctxn, wq, wout, bout, g, wpk, wpk_bstride,
-                       biasb, C, geom.MT, 2 * geom.kch);
+    hipLaunchKernelGGL(attn_fold_kernel, dim3(C / FOLD_CO, B), dim3(256), 0, st, ctxn, wq, wout, bout, g, wpk,
+                       wpk_bstride, biasb, C, geom.MT, 2 * geom.kch);
     return hipGetLastError();
 }
 

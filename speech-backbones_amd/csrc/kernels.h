@@ -67,7 +67,7 @@ struct AttnGeom {
     int tiles;          // 256-pixel tiles per sample
     int tps;            // tiles per slice (one workgroup walks a slice)
     int nslices;
-    int nrec;           // partial records per (sample, head) = nslices * 4 waves
+    int nrec;           // partial records per (sample, head) = nslices (a workgroup merges its four waves)
 };
 static inline AttnGeom attn_geom(int HW) {
     AttnGeom g;
@@ -75,7 +75,7 @@ static inline AttnGeom attn_geom(int HW) {
     int t = g.tiles / 16;
     g.tps = t < 1 ? 1 : (t > 16 ? 16 : t);
     g.nslices = (g.tiles + g.tps - 1) / g.tps;
-    g.nrec = g.nslices * 4;
+    g.nrec = g.nslices;
     return g;
 }
 static inline size_t attn_kv_packed_bytes(int C) {      // [head 4][stage][split 2][kg 2*KCH][64][8] bf16

@@ -109,31 +109,41 @@ hipError_t launch_time_mlp(const float *t, const float *freq, float pe_scale, co
 
 // ------------------------------------------------------------------------------------------------ gn_finalize
 // partials [B][nparts][groups][2] (fp32 sums of x and x^2 per workgroup tile, fixed order) ->
-// scale[b][c] = gamma[c] * rstd,  shift[b][c] = beta[c] - mean * scale.   One workgroup per sample, 32 lanes per
-// group, double accumulation, fixed reduction order => bit-reproducible run to run.
+// scale[b][c] = gamma[c] * rstd,  shift[b][c] = beta[c] - mean * scale.   One workgroup per sample, one wave per
+// group, double accumulation, fixed reduction order => bit-reproducible run to run.  The kernel is pure latency:
+// the partial loads are issued four deep before the dependent fp64 adds.
 __global__ void gn_finalize_kernel(const float *__restrict__ partials, int nparts, int groups, int C, float count,
                                    const float *__restrict__ gamma, const float *__restrict__ beta,
                                    float *__restrict__ sc, float *__restrict__ sh) {
     const int b = blockIdx.x;
-    const int g = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const int g = threadIdx.x >> 6, l = threadIdx.x & 63;
     if (g >= groups) return;
     double s1 = 0.0, s2 = 0.0;
-    const float *p = partials + (size_t)b * nparts * groups * 2;
-    for (int i = l; i < nparts; i += 32) {
-        s1 += (double)p[((size_t)i * groups + g) * 2 + 0];
-        s2 += (double)p[((size_t)i * groups + g) * 2 + 1];
+    const float2 *p = reinterpret_cast<const float2 *>(partials) + (size_t)b * nparts * groups + g;
+    for (int i0 = l; i0 < nparts; i0 += 256) {
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 64 * u;
+            v[u] = i < nparts ? p[(size_t)i * groups] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s1 += (double)v[u].x;
+            s2 += (double)v[u].y;
+        }
     }
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {
-        s1 += __shfl_xor(s1, o, 32);
-        s2 += __shfl_xor(s2, o, 32);
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
     }
     const double mean = s1 / (double)count;
     double var = s2 / (double)count - mean * mean;
     if (var < 0.0) var = 0.0;
     const double rstd = 1.0 / sqrt(var + 1e-5);
     const int gs = C / groups;
-    for (int c = g * gs + l; c < (g + 1) * gs; c += 32) {
+    for (int c = g * gs + l; c < (g + 1) * gs; c += 64) {
         const double a = (double)gamma[c] * rstd;
         sc[(size_t)b * C + c] = (float)a;
         sh[(size_t)b * C + c] = (float)((double)beta[c] - mean * a);
@@ -142,9 +152,9 @@ __global__ void gn_finalize_kernel(const float *__restrict__ partials, int npart
 
 hipError_t launch_gn_finalize(const float *partials, int nparts, int groups, int C, int HW, const float *gamma,
                               const float *beta, float *sc, float *sh, int B, hipStream_t st) {
-    if (groups * 32 > 1024) return hipErrorInvalidValue;
+    if (groups * 64 > 1024) return hipErrorInvalidValue;
     const float count = (float)((double)(C / groups) * (double)HW);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(groups * 32), 0, st, partials, nparts, groups, C, count,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(groups * 64), 0, st, partials, nparts, groups, C, count,
                        gamma, beta, sc, sh);
     return hipGetLastError();
 }
