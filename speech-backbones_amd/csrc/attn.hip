@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
                 for (int r = 0; r < 16; ++r) acc[pf][cf][r] = 0.f;
 
         for (int stage = 0; stage < a.nstage; ++stage) {
-            __syncthreads();
+            lds_barrier();
             const bool nv = tile * 256 + tid < a.HW;
 #pragma unroll
             for (int kg = 0; kg < NKG; ++kg) {
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
             }
 #pragma unroll
             for (int j = 0; j < KCH; ++j) s_w[tid + j * 256] = wregs[j];
-            __syncthreads();
+            lds_barrier();
             if (stage + 1 < a.nstage) load(tile, stage + 1);
             else if (tile + 1 < tile1) load(tile + 1, 0);
 #pragma unroll

@@ -17,6 +17,16 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // 16-byte LDS
 // no cancellation for very negative x (n -> 2 e^x).  For x > 20 tanh(softplus) == 1 in fp32.
 // Once n > 2^25 (x > ~8.7) n + 2 == n in fp32 and the ratio is 1 to an ulp, so clamping the exponent argument
 // (no overflow: e^40 squared is 5e34) replaces the reference's x > 20 branch without a compare/select.
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a full workgroup fence, which hipcc
+// lowers to s_waitcnt vmcnt(0) lgkmcnt(0): every global prefetch in flight is drained at every barrier.  With the
+// fence restricted to the local address space only lgkmcnt(0) is waited for and loads stay in flight across it.
+// Use it where the data exchanged through the barrier lives in LDS (all main loops here).
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ float mish_f(float x) {
     float e = __expf(fminf(x, 40.0f));
     float n = e * (e + 2.0f);

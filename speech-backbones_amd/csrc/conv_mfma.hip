@@ -36,7 +36,7 @@
 #ifndef GTTS_EXP
 #define GTTS_EXP 0
 #endif
-#define GTTS_SYNC() do { if (GTTS_EXP != 5) __syncthreads(); } while (0)
+#define GTTS_SYNC() do { if (GTTS_EXP != 5) lds_barrier(); } while (0)     // LDS-only fence: prefetches stay in flight
 
 namespace gtts {
 
