@@ -23,7 +23,7 @@ struct AttnCtxArgs {
     const float *x;
     const unsigned char *wkv;
     float *partials;
-    int C, HW, nstage, tiles, tps, nrec, nsplit;
+    int C, HW, nstage, tiles, tps, nrec, nsplit, B;
 };
 
 __device__ __forceinline__ void pack8_split(const float (&v)[8], u32x4 &hi, u32x4 &lo) {
@@ -48,7 +48,10 @@ __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kgl = lane >> 5;
-    const int slice = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    // XCD-banded order with the four heads of a pixel slice adjacent: they read the same x tiles (L2 hits)
+    const int nsl = gridDim.x / (4 * a.B);
+    const int wg = xcd_slot(blockIdx.x, gridDim.x);
+    const int head = wg & 3, slice = (wg >> 2) % nsl, b = (wg >> 2) / nsl;
     const int tile0 = slice * a.tps;
     const int tile1 = min(tile0 + a.tps, a.tiles);
     const float *xb = a.x + (size_t)b * a.C * a.HW;
@@ -236,9 +239,9 @@ hipError_t launch_attn_ctx(const float *x, const unsigned char *wkv, float *part
     AttnCtxArgs a;
     a.x = x; a.wkv = wkv; a.partials = partials; a.C = C; a.HW = HW;
     a.nstage = (C + 16 * ATTN_KCH - 1) / (16 * ATTN_KCH);
-    a.tiles = g.tiles; a.tps = g.tps; a.nrec = g.nrec; a.nsplit = nsplit;
-    if (nsplit > 1) hipLaunchKernelGGL(attn_ctx_kernel<2>, dim3(g.nslices, 4, B), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(attn_ctx_kernel<1>, dim3(g.nslices, 4, B), dim3(256), 0, st, a);
+    a.tiles = g.tiles; a.tps = g.tps; a.nrec = g.nrec; a.nsplit = nsplit; a.B = B;
+    if (nsplit > 1) hipLaunchKernelGGL(attn_ctx_kernel<2>, dim3(g.nslices * 4 * B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(attn_ctx_kernel<1>, dim3(g.nslices * 4 * B), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

@@ -27,6 +27,17 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// Linear workgroup id -> position in an XCD-banded order: id % 8 is the XCD the hardware picks, id / 8 the order of
+// arrival there.  Bijective for any n (the first n % 8 bands are one longer).  GTTS_XCD_BANDS=0 keeps the identity.
+#ifndef GTTS_XCD_BANDS
+#define GTTS_XCD_BANDS 1
+#endif
+__device__ __forceinline__ int xcd_slot(int id, int n) {
+    if (!GTTS_XCD_BANDS) return id;
+    const int q = n >> 3, r = n & 7, xcd = id & 7, k = id >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 __device__ __forceinline__ float mish_f(float x) {
     float e = __expf(fminf(x, 40.0f));
     float n = e * (e + 2.0f);

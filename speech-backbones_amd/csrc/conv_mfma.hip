@@ -88,9 +88,17 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kg_l = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const int b = blockIdx.z;
-    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
-    int cot = blockIdx.y, phase = 0;
+    // Workgroup -> (sample, pixel tile, cout tile / phase).  The hardware deals consecutive workgroup ids round-robin
+    // to the 8 XCDs (each with its own L2); xcd_slot() turns that into 8 contiguous bands, and inside a band the
+    // workgroups that read the same input tile (cout tiles, transposed-conv phases) and then the row-neighbour tiles
+    // (shared halo rows) are adjacent, so the re-reads hit the XCD's L2 instead of HBM.
+    const int ny = gridDim.x / (a.tiles_x * a.tiles_y * a.B);       // cout tiles (x 4 phases)
+    int wg = xcd_slot(blockIdx.x, gridDim.x);
+    const int by = wg % ny; wg /= ny;
+    const int tile = wg % (a.tiles_x * a.tiles_y);
+    const int b = wg / (a.tiles_x * a.tiles_y);
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    int cot = by, phase = 0;
     if (MODE == CONV_UP) { phase = cot & 3; cot >>= 2; }
     const int ncot = (a.cout + MT - 1) / MT;
     const int ph_y = phase >> 1, ph_x = phase & 1;
@@ -453,7 +461,7 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
                         }
                     }
                 }
-                float *p = a.partials + (((size_t)b * a.nparts + blockIdx.x) * a.groups + g) * 2;
+                float *p = a.partials + (((size_t)b * a.nparts + tile) * a.groups + g) * 2;
                 p[0] = s1;
                 p[1] = s2;
             }
@@ -461,358 +469,6 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
     }
 }
 
-
-// =====================================================================================================
-// conv_pipe_kernel -- software-pipelined variant used for the MFMA-bound 3x3 / transposed convolutions.
-//
-// Same tiling, LDS images and epilogue as conv_mfma_kernel, but the activation tile and the weight stage are
-// double-buffered in LDS so that
-//   * there is ONE barrier per weight stage (the next stage's weights are written to the other buffer at the top
-//     of a stage and its global load for the stage after that is issued right behind);
-//   * the GroupNorm/Mish/mask/split transform of chunk c+1 is spread over the stages of chunk c and sits in the
-//     same instruction stream as that stage's MFMAs (VALU and the matrix pipe run concurrently), writing the
-//     other activation buffer; its global loads for chunk c+2 are issued as soon as the registers are free.
-// No LDS-DMA is used, so plain loads stay in flight across the barriers (counted vmcnt waits only).
-template <int MODE, int WM, int WN, int MF, int KCH, int PRO, int EPI, int NSPLIT>
-__global__ __launch_bounds__(256, 2) void conv_pipe_kernel(const ConvArgs a) {
-    using C = ConvCfg<MODE, WM, WN, MF, KCH>;
-    constexpr int MT = C::MT, TR = C::TR, TC = C::TC, NST = C::NST, TPS = C::TPS, NKG = C::NKG;
-    constexpr int HC = C::HC, NPIX = C::NPIX, AITER = C::AITER, WBLK16 = C::WBLK16, WITER = C::WITER;
-    constexpr int ABUF = NKG * NPIX + 1;                // 16-byte slots per activation buffer (+1 dump slot)
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32x4 *s_ah = reinterpret_cast<u32x4 *>(smem);      // [2 buffers][NKG][NPIX]  hi
-    u32x4 *s_al = s_ah + 2 * ABUF;                      // [2 buffers][NKG][NPIX]  lo
-    u32x4 *s_w = s_al + 2 * ABUF;                       // [2 buffers][split][tap][kg][MT]
-    const int cpad = a.nchunk * 8 * NKG;
-    float *s_par = reinterpret_cast<float *>(s_w + 2 * WBLK16);
-    float *s_red = s_par + (PRO == PRO_GN ? 3 * cpad : 0);
-    float *s_epi = s_red + 4 * 2 * 4 * 2;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, kg_l = lane >> 5;
-    const int wm = wave / WN, wn = wave % WN;
-    const int b = blockIdx.z;
-    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
-    int cot = blockIdx.y, phase = 0;
-    if (MODE == CONV_UP) { phase = cot & 3; cot >>= 2; }
-    const int ncot = (a.cout + MT - 1) / MT;
-    const int ph_y = phase >> 1, ph_x = phase & 1;
-    const int y0 = ty * TR, x0 = tx * TC;
-    const int iy0 = MODE == CONV_P1 ? y0 : (MODE == CONV_DN ? 2 * y0 - 1 : y0 - 1);
-    const int ix0 = MODE == CONV_P1 ? x0 : (MODE == CONV_DN ? 2 * x0 - 1 : x0 - 1);
-    const int HWin = a.Hin * a.Win;
-
-    if (PRO == PRO_GN) {
-        for (int i = tid; i < cpad; i += 256) {
-            const bool ok = i < a.cin;
-            const int ic = ok ? i : 0;
-            const float v0 = a.sc[(size_t)b * a.cin + ic], v1 = a.sh[(size_t)b * a.cin + ic];
-            const float v2 = a.tb[(size_t)b * a.tb_stride + ic];
-            s_par[i] = ok ? v0 : 0.f;
-            s_par[cpad + i] = ok ? v1 : 0.f;
-            s_par[2 * cpad + i] = ok ? v2 : 0.f;
-        }
-    }
-    for (int i = tid; i < MT; i += 256) {
-        const int co = cot * MT + i;
-        s_epi[i] = a.bias[(size_t)b * a.bias_bstride + co];
-        if (EPI == EPI_TAIL) {
-            s_epi[MT + i] = a.esc[(size_t)b * a.cout + co];
-            s_epi[2 * MT + i] = a.esh[(size_t)b * a.cout + co];
-        }
-    }
-
-    int it_goff[AITER];
-    float it_m[AITER];
-#pragma unroll
-    for (int it = 0; it < AITER; ++it) {
-        const int idx = tid + it * 256;
-        const bool has = idx < NKG * NPIX;
-        const int kg = idx / NPIX;
-        const int p = idx - kg * NPIX;
-        const int pr = p / HC, pc = p - pr * HC;
-        const int gy = iy0 + pr, gx = ix0 + pc;
-        const bool in = has && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
-        it_goff[it] = in ? gy * a.Win + gx : 0;
-        float m = 1.f;
-        if (PRO != PRO_PLAIN) m = a.mask[(size_t)b * a.T + ((size_t)(in ? gx : 0) << a.lvl_in)];
-        it_m[it] = in ? m : -1.f;
-    }
-
-    float araw[AITER][8];
-    auto load_item = [&](int it, int chunk) {
-        const int idx = tid + it * 256;
-        const int kg = min(idx / NPIX, NKG - 1);
-        const int cbase = chunk * (8 * NKG) + kg * 8;
-        const int nval = min(max(a.cin - cbase, 0), 8);
-        const int cb0 = nval > 0 ? cbase : 0;
-        const float *pl = (cb0 < a.c0) ? a.src0 + ((size_t)b * a.c0 + cb0) * HWin
-                                       : a.src1 + ((size_t)b * a.c1 + (cb0 - a.c0)) * HWin;
-        pl += it_goff[it];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int ii = min(i, max(nval, 1) - 1);
-            araw[it][i] = pl[(size_t)ii * HWin];
-        }
-    };
-    // transform item `it` (registers hold chunk `chunk`) into activation buffer `buf`
-    auto stage_item = [&](int it, int chunk, int buf) {
-        const int idx = tid + it * 256;
-        const int kg = min(idx / NPIX, NKG - 1);
-        const int p = idx - (idx / NPIX) * NPIX;
-        const int pr = p / HC, pc = p - pr * HC;
-        int lc = pc;
-        if (MODE == CONV_DN) lc = (pc & 1) ? 33 + (pc >> 1) : (pc >> 1);
-        const bool has = idx < NKG * NPIX;
-        const float mraw = it_m[it];
-        const bool inb = mraw >= 0.f;
-        const float m = inb ? mraw : 0.f;
-        const int cb = chunk * (8 * NKG) + kg * 8;
-        const int nval = min(max(a.cin - cb, 0), 8);
-        float sc[8], sh[8], tb[8];
-        if (PRO == PRO_GN) {
-            const float4 *q = reinterpret_cast<const float4 *>(s_par + cb);
-            const float4 *q1 = reinterpret_cast<const float4 *>(s_par + cpad + cb);
-            const float4 *q2 = reinterpret_cast<const float4 *>(s_par + 2 * cpad + cb);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float4 u = q[h], u1 = q1[h], u2 = q2[h];
-                sc[4 * h + 0] = u.x; sc[4 * h + 1] = u.y; sc[4 * h + 2] = u.z; sc[4 * h + 3] = u.w;
-                sh[4 * h + 0] = u1.x; sh[4 * h + 1] = u1.y; sh[4 * h + 2] = u1.z; sh[4 * h + 3] = u1.w;
-                tb[4 * h + 0] = u2.x; tb[4 * h + 1] = u2.y; tb[4 * h + 2] = u2.z; tb[4 * h + 3] = u2.w;
-            }
-        }
-        bf16x8 vh, vl;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float v = (inb && i < nval) ? araw[it][i] : 0.f;
-            if (PRO == PRO_MASK) {
-                v *= m;
-            } else if (PRO == PRO_GN) {
-                const float y = v * sc[i] + sh[i];
-                v = (mish_f(y) * m + tb[i]) * m;
-            }
-            __bf16 h, l;
-            split_bf16(v, h, l);
-            vh[i] = h;
-            vl[i] = l;
-        }
-        // branch-free: threads without an item write the dump slot at the end of the buffer
-        const int slot = buf * ABUF + (has ? kg * NPIX + pr * HC + lc : NKG * NPIX);
-        s_ah[slot] = *reinterpret_cast<u32x4 *>(&vh);
-        s_al[slot] = *reinterpret_cast<u32x4 *>(&vl);
-    };
-
-    const unsigned char *wbase = a.w + (size_t)b * a.w_bstride;
-    u32x4 wregs[WITER];
-    const int nstage_total = a.nchunk * NST;
-    auto load_w = [&](int g_in) {      // g = chunk * NST + stage (clamped: the tail re-loads the last block)
-        const int g = min(g_in, nstage_total - 1);
-        const int chunk = g / NST, stage = g - chunk * NST;
-        size_t blk = (((size_t)phase * a.nchunk + chunk) * NST + stage) * ncot + cot;
-        const u32x4 *gp = reinterpret_cast<const u32x4 *>(wbase + blk * (size_t)(WBLK16 * 16));
-#pragma unroll
-        for (int i = 0; i < WITER; ++i) wregs[i] = gp[tid + i * 256];
-    };
-    auto store_w = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < WITER; ++i) s_w[buf * WBLK16 + tid + i * 256] = wregs[i];
-    };
-
-    f32x16 acc[MF][2];
-#pragma unroll
-    for (int mi = 0; mi < MF; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-    // ---- prologue: chunk 0 staged, weights of stage 0 in LDS, stage 1 weights and chunk 1 activations in flight
-    load_w(0);
-#pragma unroll
-    for (int it = 0; it < AITER; ++it) load_item(it, 0);
-    __syncthreads();                     // s_par / s_epi visible
-    const int last_chunk = a.nchunk - 1;
-#pragma unroll
-    for (int it = 0; it < AITER; ++it) {
-        stage_item(it, 0, 0);
-        load_item(it, min(1, last_chunk));
-    }
-    store_w(0);
-    load_w(1);
-    __syncthreads();
-
-    const int m0 = wm * MF * 32;
-    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-        const int abuf = chunk & 1;
-#pragma unroll
-        for (int stage = 0; stage < NST; ++stage) {
-            const int g = chunk * NST + stage;
-            const int wb = g & 1;
-            // next stage's weights -> the other buffer (last read in stage g-1, all waves are past that barrier)
-            // (past the last stage this stores/loads a block nobody reads: keeps the stage one basic block)
-            store_w(wb ^ 1);
-            load_w(g + 2);
-#pragma unroll
-            for (int j = 0; j < TPS; ++j) {
-                int po[2];
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const int r = wn * 2 + ni;
-                    if (MODE == CONV_C3) po[ni] = (r + stage) * HC + j;
-                    else if (MODE == CONV_DN) po[ni] = (2 * r + stage) * HC + (j == 1 ? 33 : (j >> 1));
-                    else if (MODE == CONV_UP) {
-                        int dy = ph_y == 0 ? (stage == 0 ? 0 : -1) : (stage == 0 ? 1 : 0);
-                        int dx = ph_x == 0 ? (j == 0 ? 0 : -1) : (j == 0 ? 1 : 0);
-                        po[ni] = (r + 1 + dy) * HC + 1 + dx;
-                    } else po[ni] = r * HC;
-                }
-#pragma unroll
-                for (int kc = 0; kc < KCH; ++kc) {
-                    bf16x8 wh[MF], wl[MF], xh[2], xl[2];
-#pragma unroll
-                    for (int mi = 0; mi < MF; ++mi) {
-                        int wi = wb * WBLK16 + (j * NKG + kc * 2 + kg_l) * MT + m0 + mi * 32 + l31;
-                        wh[mi] = *reinterpret_cast<const bf16x8 *>(&s_w[wi]);
-                        if (NSPLIT > 1) wl[mi] = *reinterpret_cast<const bf16x8 *>(&s_w[wi + TPS * NKG * MT]);
-                    }
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        int xi = abuf * ABUF + (kc * 2 + kg_l) * NPIX + po[ni] + l31;
-                        xh[ni] = *reinterpret_cast<const bf16x8 *>(&s_ah[xi]);
-                        if (NSPLIT > 1) xl[ni] = *reinterpret_cast<const bf16x8 *>(&s_al[xi]);
-                    }
-#pragma unroll
-                    for (int mi = 0; mi < MF; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < 2; ++ni) {
-                            if (NSPLIT > 1) {
-                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[mi], xh[ni], acc[mi][ni], 0, 0, 0);
-                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[mi], xl[ni], acc[mi][ni], 0, 0, 0);
-                            }
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[mi], xh[ni], acc[mi][ni], 0, 0, 0);
-                        }
-                }
-                // the share of chunk+1's staging that belongs to this stage rides behind the first tap's MFMAs
-                if (j == 0) {
-#pragma unroll
-                    for (int it = 0; it < AITER; ++it) {
-                        if (it % NST == stage) {      // compile-time; chunk indices clamped -> no branches
-                            stage_item(it, min(chunk + 1, last_chunk), abuf ^ 1);
-                            load_item(it, min(chunk + 2, last_chunk));
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
-
-    // ---------------------------------------------------------------- epilogue (as conv_mfma_kernel)
-    const int HWout = a.Hout * a.Wout;
-    float st1[MF][4], st2[MF][4];
-#pragma unroll
-    for (int mi = 0; mi < MF; ++mi)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { st1[mi][q] = 0.f; st2[mi][q] = 0.f; }
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int r = wn * 2 + ni;
-        int oy = y0 + r, ox = x0 + l31;
-        if (MODE == CONV_UP) { oy = 2 * oy + ph_y; ox = 2 * ox + ph_x; }
-        const bool pix_ok = oy < a.Hout && ox < a.Wout;
-        if (pix_ok) {
-            float m_out = 0.f;
-            if (EPI == EPI_TAIL) m_out = a.mask[(size_t)b * a.T + ((size_t)ox << a.lvl_out)];
-            const size_t obase = ((size_t)b * a.cout + cot * MT) * HWout + (size_t)oy * a.Wout + ox;
-#pragma unroll
-            for (int mi = 0; mi < MF; ++mi) {
-                float ex[16];
-                if (EPI == EPI_TAIL || EPI == EPI_ATTN) {
-                    const float *ep = (EPI == EPI_TAIL ? a.eh : a.eres) + obase;
-#pragma unroll
-                    for (int rg = 0; rg < 16; ++rg) {
-                        const int col = m0 + mi * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kg_l;
-                        ex[rg] = ep[(size_t)col * HWout];
-                    }
-                }
-#pragma unroll
-                for (int rg = 0; rg < 16; ++rg) {
-                    const int col = m0 + mi * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kg_l;
-                    float v = acc[mi][ni][rg] + s_epi[col];
-                    if (EPI == EPI_TAIL) {
-                        const float y = ex[rg] * s_epi[MT + col] + s_epi[2 * MT + col];
-                        v += mish_f(y) * m_out;
-                    } else if (EPI == EPI_ATTN) {
-                        v += ex[rg];
-                    }
-                    a.out[obase + (size_t)col * HWout] = v;
-                    if (EPI == EPI_STATS) {
-                        st1[mi][rg >> 2] += v;
-                        st2[mi][rg >> 2] += v * v;
-                    }
-                }
-            }
-        }
-    }
-    if (EPI == EPI_STATS) {
-        const int gs = a.cout / a.groups;
-#pragma unroll
-        for (int mi = 0; mi < MF; ++mi)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float s1 = wave_sum(st1[mi][q]);
-                float s2 = wave_sum(st2[mi][q]);
-                if (lane == 0) {
-                    s_red[((wave * MF + mi) * 4 + q) * 2 + 0] = s1;
-                    s_red[((wave * MF + mi) * 4 + q) * 2 + 1] = s2;
-                }
-            }
-        __syncthreads();
-        const int gpw = MT / gs > 0 ? MT / gs : 1;
-        if (tid < gpw) {
-            const int g = (cot * MT) / gs + tid;
-            if (g < a.groups) {
-                float s1 = 0.f, s2 = 0.f;
-                for (int w = 0; w < 4; ++w) {
-                    const int wmm = w / WN;
-                    for (int mi = 0; mi < MF; ++mi) {
-                        const int cbase = cot * MT + (wmm * MF + mi) * 32;
-                        for (int q = 0; q < 4; ++q) {
-                            const int gq = (cbase + q * 8) / gs;
-                            if (gq == g) {
-                                s1 += s_red[((w * MF + mi) * 4 + q) * 2 + 0];
-                                s2 += s_red[((w * MF + mi) * 4 + q) * 2 + 1];
-                            }
-                        }
-                    }
-                }
-                float *p = a.partials + (((size_t)b * a.nparts + blockIdx.x) * a.groups + g) * 2;
-                p[0] = s1;
-                p[1] = s2;
-            }
-        }
-    }
-}
-
-static inline size_t conv_pipe_smem_bytes(int npix, int nkg, int wblk16, int cin, int pro, int mt) {
-    size_t cpad = (size_t)((cin + 8 * nkg - 1) / (8 * nkg)) * 8 * nkg;
-    return (size_t)2 * (npix * nkg + 1) * 16 * 2 + (size_t)2 * wblk16 * 16 + (pro == PRO_GN ? 3 * cpad * 4 : 0) +
-           4 * 2 * 4 * 2 * 4 + (size_t)3 * mt * 4;
-}
-
-// tuning knob: GTTS_CONV_PIPE=1 selects the double-buffered kernel for the 3x3 / transposed convolutions.
-// Measured on MI355X (profiles/r01_ab_pipe.txt): 8.97 ms per U-Net call vs 8.71 ms for the single-buffered kernel at
-// 3 workgroups per CU -- the extra LDS costs one resident workgroup per CU, which cancels the saved barriers.
-static inline bool conv_pipe_enabled() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("GTTS_CONV_PIPE");
-        v = (e && e[0] == '1') ? 1 : 0;
-    }
-    return v == 1;
-}
 
 template <int MODE, int WM, int WN, int MF, int KCH, int PRO, int EPI, int NSPLIT, int FULLC>
 static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
@@ -824,7 +480,7 @@ static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
     a.tiles_x = (tw + C::TC - 1) / C::TC;
     a.tiles_y = (th + C::TR - 1) / C::TR;
     const int ncot = (a.cout + C::MT - 1) / C::MT;
-    dim3 grid(a.tiles_x * a.tiles_y, ncot * (MODE == CONV_UP ? 4 : 1), a.B);
+    dim3 grid(a.tiles_x * a.tiles_y * ncot * (MODE == CONV_UP ? 4 : 1) * a.B);
     if (a.cout % C::MT != 0) return hipErrorInvalidValue;   // epilogue assumes whole output-channel tiles
     size_t smem = conv_smem_bytes(C::NPIX, C::NKG, C::WBLK16, a.cin, PRO, C::MT);
     static size_t attr_set = 0;
@@ -834,19 +490,6 @@ static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr_set = smem;
-    }
-    if constexpr ((MODE == CONV_C3 && EPI == EPI_STATS) || MODE == CONV_UP) if (conv_pipe_enabled()) {
-        size_t smem2 = conv_pipe_smem_bytes(C::NPIX, C::NKG, C::WBLK16, a.cin, PRO, C::MT);
-        static size_t attr2 = 0;
-        if (smem2 > attr2) {
-            hipError_t e = hipFuncSetAttribute(
-                reinterpret_cast<const void *>(&conv_pipe_kernel<MODE, WM, WN, MF, KCH, PRO, EPI, NSPLIT>),
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
-            if (e != hipSuccess) return e;
-            attr2 = smem2;
-        }
-        hipLaunchKernelGGL((conv_pipe_kernel<MODE, WM, WN, MF, KCH, PRO, EPI, NSPLIT>), grid, dim3(256), smem2, st, a);
-        return hipGetLastError();
     }
     hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, MF, KCH, PRO, EPI, NSPLIT, FULLC>), grid, dim3(256), smem, st, a);
     return hipGetLastError();
