@@ -149,7 +149,8 @@ int gtts_vc_tensor_info(const gtts_plan *plan, int i, int B, int T, int T_ref, c
 int gtts_plan_num_ops(const gtts_plan *plan);
 int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, const char **label, const char **kernel,
                       double *flops, double *bytes);
-/* on != 0: every later estimator / sampler call brackets each op launch with hipEventRecord on the call's stream. */
+/* on != 0: every later estimator / sampler call brackets each op launch with hipEventRecord on the call's stream;
+ * while profiling, the sampler runs the batch unsplit on that one stream (no sub-batch streams). */
 int gtts_profile_enable(gtts_plan *plan, int on);
 /* Synchronises the recorded events, adds elapsed milliseconds and launch counts per op into the two arrays
  * (length gtts_plan_num_ops) and clears the record. */

@@ -906,7 +906,9 @@ extern "C" int gtts_reverse_diffusion(const gtts_plan *plan, const void *packed,
     // Utterances are independent, so the batch is split in two halves that run the whole N-step loop side by side
     // on two streams: the tail of one half's kernel overlaps the other half's next kernel, and HBM-bound kernels
     // overlap MFMA-bound ones.  Results are bit-identical to the unsplit run (no operation mixes batch entries).
-    const int nhalf = sampler_parts(B);
+    // per-op profiling (gtts_profile_enable) runs the batch unsplit: one launch per op owns the GPU, so an op's
+    // HIP-event duration and its whole-batch algorithmic work describe the same thing
+    const int nhalf = p->prof_on ? 1 : sampler_parts(B);
     const int Bh0 = (B + nhalf - 1) / nhalf;
     layout_workspace(p, Bh0, T, std::max(Bh0, 4096));
     const size_t ws_half = align_up(p->ws_bytes, 256);
