@@ -38,6 +38,23 @@
 #endif
 #define GTTS_SYNC() do { if (GTTS_EXP != 5) lds_barrier(); } while (0)     // LDS-only fence: prefetches stay in flight
 
+// GTTS_TRACE=1 (diagnostic builds only): per-wave s_memtime phase sums of the 3x3 GroupNorm kernel, read back with
+// gtts_debug_trace().  Phases: 0 top-of-chunk barrier, 1 activation transform + LDS write, 2 weight wait + LDS write,
+// 3 barrier after the weight write, 4 prefetch issue + fragment reads + MFMAs, 5 inter-stage barrier, 6 whole loop.
+#ifndef GTTS_TRACE
+#define GTTS_TRACE 0
+#endif
+// (s_setprio by phase -- staging high or MFMA high -- was measured: no effect, +-0.5 %.)
+#if GTTS_TRACE
+__device__ unsigned long long g_conv_trace[64 * 4 * 8];      // zero-initialised; rewritten by every traced launch
+extern "C" int gtts_debug_trace(unsigned long long *dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_conv_trace), sizeof(unsigned long long) * (n < 2048 ? n : 2048));
+}
+#define TR_MARK(ph) do { if (tr_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tr_sum[ph] += t_ - tr_last; tr_last = t_; } } while (0)
+#else
+#define TR_MARK(ph) do { } while (0)
+#endif
+
 namespace gtts {
 
 template <int MODE, int WM, int WN, int MF, int KCH>
@@ -234,9 +251,19 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
     load_act(0);
 
     const int m0 = wm * MF * 32;
+#if GTTS_TRACE
+    const bool tr_on = MODE == CONV_C3 && PRO == PRO_GN && WM == 2 && a.cin == 128 && a.cout == 128 && (blockIdx.x % 97) == 5 && blockIdx.x / 97 < 64;
+    unsigned long long tr_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long tr_t0 = tr_last;
+#endif
 
     for (int chunk = 0; chunk < a.nchunk; ++chunk) {
         GTTS_SYNC();   // previous chunk's MFMAs are done with s_a* / s_w (and s_par is written)
+        TR_MARK(0);
+#if GTTS_TRACE
+        __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0): separates the load wait (phase 7) from the transform (phase 1)
+        TR_MARK(7);
+#endif
         // ---- transform + split + stage the activation tile of this chunk (straight-line code)
 #pragma unroll
         for (int it = 0; it < (GTTS_EXP == 3 ? 0 : AITER); ++it) {
@@ -303,12 +330,15 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
                 s_al[slot] = *reinterpret_cast<u32x4 *>(&vl);
             }
         }
+        TR_MARK(1);
 #pragma unroll
         for (int stage = 0; stage < NST; ++stage) {
-            if (stage > 0) GTTS_SYNC();   // previous stage's MFMAs are done with s_w
+            if (stage > 0) { GTTS_SYNC(); TR_MARK(5); }   // previous stage's MFMAs are done with s_w
 #pragma unroll
             for (int i = 0; i < (GTTS_EXP == 4 ? 0 : WITER); ++i) s_w[tid + i * 256] = wregs[i];
+            TR_MARK(2);
             GTTS_SYNC();
+            TR_MARK(3);
             // ---- prefetch behind the MFMAs: next weight block (one stage ahead) and, as early as the staging
             // registers are free again, the next activation chunk (a whole chunk of MFMAs ahead)
             if (GTTS_EXP == 4) {
@@ -374,8 +404,15 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
 #endif
                 }
             }
+            TR_MARK(4);
         }
     }
+#if GTTS_TRACE
+    if (tr_on && lane == 0) {
+        tr_sum[6] = __builtin_amdgcn_s_memtime() - tr_t0;
+        for (int i = 0; i < 8; ++i) g_conv_trace[((blockIdx.x / 97) * 4 + wave) * 8 + i] = tr_sum[i];
+    }
+#endif
 
     // ---------------------------------------------------------------- epilogue
     const int HWout = a.Hout * a.Wout;

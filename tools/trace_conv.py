@@ -1,0 +1,38 @@
+"""Diagnostic: per-phase s_memtime sums of the 3x3 GroupNorm conv kernel (library built with -DGTTS_TRACE=1)."""
+import ctypes
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+S = importlib.import_module("speech-backbones_amd")
+from oracle import gradtts_oracle as O  # noqa: E402  (weights only; this is a diagnostic, not the product path)
+
+B, T = 16, 1024
+dev = torch.device("cuda:0")
+sd = O.make_estimator_state(seed=0)
+plan = S.Plan(n_spks=1)
+packed = plan.pack(sd, dev)
+g = torch.Generator().manual_seed(0)
+x = torch.randn(B, 80, T, generator=g).to(dev)
+mu = torch.randn(B, 80, T, generator=g).to(dev)
+mask = torch.ones(B, 1, T, device=dev)
+t = torch.full((B,), 0.5, device=dev)
+for _ in range(2):
+    out = plan.estimator_forward(packed, x, mask, mu, t)
+torch.cuda.synchronize()
+lib = S._lib.lib()
+buf = (ctypes.c_ulonglong * 2048)()
+rc = lib.gtts_debug_trace(buf, 2048)
+a = np.array(buf[:], dtype=np.float64).reshape(64, 4, 8)
+a = a[a[:, 0, 6] > 0]
+print("rc", rc, "workgroups traced", a.shape[0], "(last GN 3x3 launch of the call)")
+names = ["top barrier", "act transform+write", "weight wait+write", "barrier after w", "prefetch+reads+MFMA", "stage barrier", "loop total", "act load wait"]
+NCH = 8.0   # traced layer: 128 -> 128 channels
+tot = a[:, :, 6].mean()
+for i, n in enumerate(names):
+    print("%-22s mean %10.0f  (%5.1f%% of loop)   per chunk %8.0f" % (n, a[:, :, i].mean(), 100 * a[:, :, i].mean() / tot, a[:, :, i].mean() / NCH))
