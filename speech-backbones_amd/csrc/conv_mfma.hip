@@ -44,11 +44,14 @@
 #ifndef GTTS_TRACE
 #define GTTS_TRACE 0
 #endif
+#ifndef GTTS_TRACE_CIN
+#define GTTS_TRACE_CIN 128      // traced layer: cin == cout == this
+#endif
 // (s_setprio by phase -- staging high or MFMA high -- was measured: no effect, +-0.5 %.)
 #if GTTS_TRACE
-__device__ unsigned long long g_conv_trace[64 * 4 * 8];      // zero-initialised; rewritten by every traced launch
+__device__ unsigned long long g_conv_trace[64 * 4 * 8 + 64 * 4 * 2];   // + [wg][wave]{prologue, epilogue}      // zero-initialised; rewritten by every traced launch
 extern "C" int gtts_debug_trace(unsigned long long *dst, int n) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_conv_trace), sizeof(unsigned long long) * (n < 2048 ? n : 2048));
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_conv_trace), sizeof(unsigned long long) * (n < 2560 ? n : 2560));
 }
 #define TR_MARK(ph) do { if (tr_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tr_sum[ph] += t_ - tr_last; tr_last = t_; } } while (0)
 #else
@@ -91,6 +94,9 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
     constexpr int MT = C::MT, TR = C::TR, TC = C::TC, NST = C::NST, TPS = C::TPS, NKG = C::NKG;
     constexpr int HC = C::HC, NPIX = C::NPIX, AITER = C::AITER, WBLK16 = C::WBLK16, WITER = C::WITER;
 
+#if GTTS_TRACE
+    const unsigned long long tr_entry = __builtin_amdgcn_s_memtime();
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4 *s_ah = reinterpret_cast<u32x4 *>(smem);      // [NKG][NPIX]  hi
     u32x4 *s_al = s_ah + NKG * NPIX;                    // [NKG][NPIX]  lo
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
 
     const int m0 = wm * MF * 32;
 #if GTTS_TRACE
-    const bool tr_on = MODE == CONV_C3 && PRO == PRO_GN && WM == 2 && a.cin == 128 && a.cout == 128 && (blockIdx.x % 97) == 5 && blockIdx.x / 97 < 64;
+    const bool tr_on = MODE == CONV_C3 && PRO == PRO_GN && a.cin == GTTS_TRACE_CIN && a.cout == GTTS_TRACE_CIN && (blockIdx.x % 97) == 5 && blockIdx.x / 97 < 64;
     unsigned long long tr_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_last = __builtin_amdgcn_s_memtime();
     const unsigned long long tr_t0 = tr_last;
 #endif
@@ -411,6 +417,7 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
     if (tr_on && lane == 0) {
         tr_sum[6] = __builtin_amdgcn_s_memtime() - tr_t0;
         for (int i = 0; i < 8; ++i) g_conv_trace[((blockIdx.x / 97) * 4 + wave) * 8 + i] = tr_sum[i];
+        g_conv_trace[2048 + ((blockIdx.x / 97) * 4 + wave) * 2] = tr_t0 - tr_entry;
     }
 #endif
 
@@ -422,6 +429,14 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
 #pragma unroll
         for (int q = 0; q < 4; ++q) { st1[mi][q] = 0.f; st2[mi][q] = 0.f; }
 
+    // Output (and the fused-tail / residual input) go through buffer descriptors of this sample's tensors: per-lane
+    // byte offset = pixel + the lane's 4-channel sub-row, per-channel offset in an SGPR -> no 64-bit VALU address
+    // arithmetic per access.
+    const int out_bytes = a.cout * HWout * 4;
+    const __amdgpu_buffer_rsrc_t rs_out = uniform_rsrc(a.out + (size_t)b * a.cout * HWout, out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_ex =
+        uniform_rsrc((EPI == EPI_TAIL ? a.eh : (EPI == EPI_ATTN ? a.eres : a.out)) + (size_t)b * a.cout * HWout, out_bytes);
+    const int ch0 = __builtin_amdgcn_readfirstlane(cot * MT + m0);     // first channel of this wave's fragments
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int r = wn * 2 + ni;
@@ -431,16 +446,15 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
         if (pix_ok) {      // one exec-mask region per row; straight-line code inside
             float m_out = 0.f;
             if (EPI == EPI_TAIL) m_out = a.mask[(size_t)b * a.T + ((size_t)ox << a.lvl_out)];
-            const size_t obase = ((size_t)b * a.cout + cot * MT) * HWout + (size_t)oy * a.Wout + ox;
+            const int voff = (oy * a.Wout + ox + 4 * kg_l * HWout) * 4;
 #pragma unroll
             for (int mi = 0; mi < MF; ++mi) {
                 float ex[16];
                 if (EPI == EPI_TAIL || EPI == EPI_ATTN) {
-                    const float *ep = (EPI == EPI_TAIL ? a.eh : a.eres) + obase;
 #pragma unroll
                     for (int rg = 0; rg < 16; ++rg) {
-                        const int col = m0 + mi * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kg_l;
-                        ex[rg] = ep[(size_t)col * HWout];
+                        const int soff = (ch0 + mi * 32 + (rg & 3) + 8 * (rg >> 2)) * HWout * 4;
+                        ex[rg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ex, voff, soff, 0));
                     }
                 }
 #pragma unroll
@@ -453,7 +467,8 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
                     } else if (EPI == EPI_ATTN) {
                         v += ex[rg];
                     }
-                    a.out[obase + (size_t)col * HWout] = v;
+                    const int soff = (ch0 + mi * 32 + (rg & 3) + 8 * (rg >> 2)) * HWout * 4;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs_out, voff, soff, 0);
                     if (EPI == EPI_STATS) {
                         // octet rg>>2 of this 32-channel fragment (static index); octets -> groups below
                         st1[mi][rg >> 2] += v;
@@ -504,6 +519,10 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
             }
         }
     }
+#if GTTS_TRACE
+    if (tr_on && lane == 0)
+        g_conv_trace[2048 + ((blockIdx.x / 97) * 4 + wave) * 2 + 1] = __builtin_amdgcn_s_memtime() - tr_t0 - tr_sum[6];
+#endif
 }
 
 

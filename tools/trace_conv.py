@@ -26,13 +26,18 @@ for _ in range(2):
     out = plan.estimator_forward(packed, x, mask, mu, t)
 torch.cuda.synchronize()
 lib = S._lib.lib()
-buf = (ctypes.c_ulonglong * 2048)()
-rc = lib.gtts_debug_trace(buf, 2048)
-a = np.array(buf[:], dtype=np.float64).reshape(64, 4, 8)
-a = a[a[:, 0, 6] > 0]
+buf = (ctypes.c_ulonglong * 2560)()
+rc = lib.gtts_debug_trace(buf, 2560)
+raw = np.array(buf[:], dtype=np.float64)
+a = raw[:2048].reshape(64, 4, 8)
+pe = raw[2048:].reshape(64, 4, 2)
+sel = a[:, 0, 6] > 0
+a, pe = a[sel], pe[sel]
 print("rc", rc, "workgroups traced", a.shape[0], "(last GN 3x3 launch of the call)")
 names = ["top barrier", "act transform+write", "weight wait+write", "barrier after w", "prefetch+reads+MFMA", "stage barrier", "loop total", "act load wait"]
-NCH = 8.0   # traced layer: 128 -> 128 channels
+NCH = float(os.environ.get('TRACE_CIN', '128')) / 16   # traced layer: cin == cout == TRACE_CIN
 tot = a[:, :, 6].mean()
 for i, n in enumerate(names):
     print("%-22s mean %10.0f  (%5.1f%% of loop)   per chunk %8.0f" % (n, a[:, :, i].mean(), 100 * a[:, :, i].mean() / tot, a[:, :, i].mean() / NCH))
+print("prologue (entry -> loop)   mean %10.0f  (%5.1f%% of loop)" % (pe[:, :, 0].mean(), 100 * pe[:, :, 0].mean() / tot))
+print("epilogue (loop -> exit)    mean %10.0f  (%5.1f%% of loop)" % (pe[:, :, 1].mean(), 100 * pe[:, :, 1].mean() / tot))
