@@ -49,9 +49,9 @@
 #endif
 // (s_setprio by phase -- staging high or MFMA high -- was measured: no effect, +-0.5 %.)
 #if GTTS_TRACE
-__device__ unsigned long long g_conv_trace[64 * 4 * 8 + 64 * 4 * 2];   // + [wg][wave]{prologue, epilogue}      // zero-initialised; rewritten by every traced launch
+__device__ unsigned long long g_conv_trace[64 * 4 * 8 + 64 * 4 * 2 + 64 * 4 * 4];   // + [wg][wave]{prologue, epilogue} + epilogue parts      // zero-initialised; rewritten by every traced launch
 extern "C" int gtts_debug_trace(unsigned long long *dst, int n) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_conv_trace), sizeof(unsigned long long) * (n < 2560 ? n : 2560));
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_conv_trace), sizeof(unsigned long long) * (n < 3584 ? n : 3584));
 }
 #define TR_MARK(ph) do { if (tr_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tr_sum[ph] += t_ - tr_last; tr_last = t_; } } while (0)
 #else
@@ -129,35 +129,6 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
     const int iy0 = MODE == CONV_P1 ? y0 : (MODE == CONV_DN ? 2 * y0 - 1 : y0 - 1);
     const int ix0 = MODE == CONV_P1 ? x0 : (MODE == CONV_DN ? 2 * x0 - 1 : x0 - 1);
     const int HWin = a.Hin * a.Win;
-
-    // ---- per-(sample, channel) prologue parameters -> LDS (visible after the first barrier)
-    if (PRO == PRO_GN || PRO == PRO_IGLU) {
-        const int cs = PRO == PRO_IGLU ? 2 * a.cin : a.cin;      // channels of the raw source tensor
-        for (int i = tid; i < cpad; i += 256) {
-            const bool ok = i < a.cin;
-            const int ic = ok ? i : 0;
-            const float v0 = a.sc[(size_t)b * cs + ic], v1 = a.sh[(size_t)b * cs + ic];
-            const float v2 = a.tb ? a.tb[(size_t)b * a.tb_stride + ic] : 0.f;
-            s_par[i] = ok ? v0 : 0.f;
-            s_par[cpad + i] = ok ? v1 : 0.f;
-            s_par[2 * cpad + i] = ok ? v2 : 0.f;
-            if (PRO == PRO_IGLU) {
-                const float v3 = a.sc[(size_t)b * cs + a.cin + ic], v4 = a.sh[(size_t)b * cs + a.cin + ic];
-                s_par[3 * cpad + i] = ok ? v3 : 0.f;
-                s_par[4 * cpad + i] = ok ? v4 : 0.f;
-            }
-        }
-    }
-
-    // ---- per-output-channel epilogue parameters -> LDS (read after many barriers)
-    for (int i = tid; i < MT; i += 256) {
-        const int co = cot * MT + i;       // host guarantees cout % MT == 0
-        s_epi[i] = a.bias[(size_t)b * a.bias_bstride + co];
-        if (EPI == EPI_TAIL) {
-            s_epi[MT + i] = a.esc[(size_t)b * a.cout + co];
-            s_epi[2 * MT + i] = a.esh[(size_t)b * a.cout + co];
-        }
-    }
 
     // ---- staging items: geometry is chunk-invariant.  Out-of-image items load from offset 0 (valid memory)
     // and are zeroed by a select.
@@ -255,6 +226,38 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
 
     load_w(0, 0);
     load_act(0);
+
+    // (filled after the first tile's loads are in flight: the parameter loads share one memory round trip with them
+    // instead of adding two serialized ones in front)
+    // ---- per-(sample, channel) prologue parameters -> LDS (visible after the first barrier)
+    if (PRO == PRO_GN || PRO == PRO_IGLU) {
+        const int cs = PRO == PRO_IGLU ? 2 * a.cin : a.cin;      // channels of the raw source tensor
+        for (int i = tid; i < cpad; i += 256) {
+            const bool ok = i < a.cin;
+            const int ic = ok ? i : 0;
+            const float v0 = a.sc[(size_t)b * cs + ic], v1 = a.sh[(size_t)b * cs + ic];
+            const float v2 = a.tb ? a.tb[(size_t)b * a.tb_stride + ic] : 0.f;
+            s_par[i] = ok ? v0 : 0.f;
+            s_par[cpad + i] = ok ? v1 : 0.f;
+            s_par[2 * cpad + i] = ok ? v2 : 0.f;
+            if (PRO == PRO_IGLU) {
+                const float v3 = a.sc[(size_t)b * cs + a.cin + ic], v4 = a.sh[(size_t)b * cs + a.cin + ic];
+                s_par[3 * cpad + i] = ok ? v3 : 0.f;
+                s_par[4 * cpad + i] = ok ? v4 : 0.f;
+            }
+        }
+    }
+
+    // ---- per-output-channel epilogue parameters -> LDS (read after many barriers)
+    for (int i = tid; i < MT; i += 256) {
+        const int co = cot * MT + i;       // host guarantees cout % MT == 0
+        s_epi[i] = a.bias[(size_t)b * a.bias_bstride + co];
+        if (EPI == EPI_TAIL) {
+            s_epi[MT + i] = a.esc[(size_t)b * a.cout + co];
+            s_epi[2 * MT + i] = a.esh[(size_t)b * a.cout + co];
+        }
+    }
+
 
     const int m0 = wm * MF * 32;
 #if GTTS_TRACE
@@ -479,10 +482,15 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
         }
     }
 
+#if GTTS_TRACE
+    unsigned long long tr_e[4] = {0, 0, 0, 0};
+    if (tr_on) tr_e[0] = __builtin_amdgcn_s_memtime();
+#endif
     if (EPI == EPI_STATS) {
         // wave reduce -> LDS -> fixed-order combine: one partial per (workgroup, group), deterministic
         const int gs = a.cout / a.groups;                   // channels per GroupNorm group
-        __syncthreads();
+        // (s_red is not touched by the main loop: no barrier needed before writing it; the one below orders LDS only,
+        // a full __syncthreads() would also wait for the 64 output stores of every lane to complete)
 #pragma unroll
         for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
@@ -494,7 +502,13 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
                     s_red[((wave * MF + mi) * 4 + q) * 2 + 1] = s2;
                 }
             }
-        __syncthreads();
+#if GTTS_TRACE
+        if (tr_on) tr_e[1] = __builtin_amdgcn_s_memtime();
+#endif
+        lds_barrier();
+#if GTTS_TRACE
+        if (tr_on) tr_e[2] = __builtin_amdgcn_s_memtime();
+#endif
         const int gpw = MT / gs > 0 ? MT / gs : 1;     // groups covered by this workgroup
         if (tid < gpw) {
             const int g = (cot * MT) / gs + tid;       // global group index
@@ -520,8 +534,15 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
         }
     }
 #if GTTS_TRACE
-    if (tr_on && lane == 0)
-        g_conv_trace[2048 + ((blockIdx.x / 97) * 4 + wave) * 2 + 1] = __builtin_amdgcn_s_memtime() - tr_t0 - tr_sum[6];
+    if (tr_on && lane == 0) {
+        const unsigned long long tend = __builtin_amdgcn_s_memtime();
+        g_conv_trace[2048 + ((blockIdx.x / 97) * 4 + wave) * 2 + 1] = tend - tr_t0 - tr_sum[6];
+        unsigned long long *q = g_conv_trace + 2560 + ((blockIdx.x / 97) * 4 + wave) * 4;
+        q[0] = tr_e[0] - tr_t0 - tr_sum[6];      // bias + stores issued
+        q[1] = tr_e[1] - tr_e[0];                // wave reductions + s_red
+        q[2] = tr_e[2] - tr_e[1];                // barrier
+        q[3] = tend - tr_e[2];                   // final combine
+    }
 #endif
 }
 

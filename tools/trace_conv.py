@@ -26,13 +26,14 @@ for _ in range(2):
     out = plan.estimator_forward(packed, x, mask, mu, t)
 torch.cuda.synchronize()
 lib = S._lib.lib()
-buf = (ctypes.c_ulonglong * 2560)()
-rc = lib.gtts_debug_trace(buf, 2560)
+buf = (ctypes.c_ulonglong * 3584)()
+rc = lib.gtts_debug_trace(buf, 3584)
 raw = np.array(buf[:], dtype=np.float64)
 a = raw[:2048].reshape(64, 4, 8)
-pe = raw[2048:].reshape(64, 4, 2)
+pe = raw[2048:2560].reshape(64, 4, 2)
+ep = raw[2560:].reshape(64, 4, 4)
 sel = a[:, 0, 6] > 0
-a, pe = a[sel], pe[sel]
+a, pe, ep = a[sel], pe[sel], ep[sel]
 print("rc", rc, "workgroups traced", a.shape[0], "(last GN 3x3 launch of the call)")
 names = ["top barrier", "act transform+write", "weight wait+write", "barrier after w", "prefetch+reads+MFMA", "stage barrier", "loop total", "act load wait"]
 NCH = float(os.environ.get('TRACE_CIN', '128')) / 16   # traced layer: cin == cout == TRACE_CIN
@@ -41,3 +42,5 @@ for i, n in enumerate(names):
     print("%-22s mean %10.0f  (%5.1f%% of loop)   per chunk %8.0f" % (n, a[:, :, i].mean(), 100 * a[:, :, i].mean() / tot, a[:, :, i].mean() / NCH))
 print("prologue (entry -> loop)   mean %10.0f  (%5.1f%% of loop)" % (pe[:, :, 0].mean(), 100 * pe[:, :, 0].mean() / tot))
 print("epilogue (loop -> exit)    mean %10.0f  (%5.1f%% of loop)" % (pe[:, :, 1].mean(), 100 * pe[:, :, 1].mean() / tot))
+for i, n in enumerate(["  bias + output stores issued", "  wave reductions + s_red", "  barrier", "  final combine"]):
+    print("%-30s mean %10.0f" % (n, ep[:, :, i].mean()))
