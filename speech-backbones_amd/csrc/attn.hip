@@ -39,7 +39,8 @@ __device__ __forceinline__ void pack8_split(const float (&v)[8], u32x4 &hi, u32x
     lo = *reinterpret_cast<u32x4 *>(&vl);
 }
 
-template <int NSPLIT>
+// FULLC: C is a multiple of 32 (every staged channel exists)
+template <int NSPLIT, int FULLC>
 __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
     constexpr int KCH = ATTN_KCH, NKG = 2 * KCH;
     __shared__ __attribute__((aligned(16))) u32x4 s_ah[NKG * 256];
@@ -59,14 +60,27 @@ __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
 
     float raw[NKG][8];
     u32x4 wregs[KCH];
-    // unconditional loads from clamped addresses; out-of-range pixels / channels are zeroed at the split
+    // Buffer loads: the lane's pixel is the per-lane byte offset, the channel offset is an SGPR; pixels >= HW get a
+    // per-lane offset past the end of the descriptor and read 0 from the bounds check (which covers the per-lane
+    // offset only, so a channel >= C is clamped and zeroed explicitly -- never the case when C % 32 == 0).
+    const unsigned long long xaddr = reinterpret_cast<unsigned long long>(xb);
+    const int xbytes = a.C * a.HW * 4;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void *>(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32)) << 32) |
+                                 __builtin_amdgcn_readfirstlane((unsigned)xaddr)),
+        0, __builtin_amdgcn_readfirstlane(xbytes), 0x00020000);
     auto load = [&](int tile, int stage) {
-        const int n = min(tile * 256 + tid, a.HW - 1);
+        const int n = tile * 256 + tid;
+        const int voff = n < a.HW ? n * 4 : xbytes;
 #pragma unroll
         for (int kg = 0; kg < NKG; ++kg) {
             const int cb = stage * 16 * KCH + kg * 8;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) raw[kg][i] = xb[(size_t)min(cb + i, a.C - 1) * a.HW + n];
+            for (int i = 0; i < 8; ++i) {
+                const int c = FULLC ? cb + i : min(cb + i, a.C - 1);
+                const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, voff, c * a.HW * 4, 0));
+                raw[kg][i] = (FULLC || cb + i < a.C) ? v : 0.f;
+            }
         }
         const u32x4 *g = wblk + (size_t)stage * (2 * NKG * 64);
 #pragma unroll
@@ -92,13 +106,9 @@ __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
 
         for (int stage = 0; stage < a.nstage; ++stage) {
             lds_barrier();
-            const bool nv = tile * 256 + tid < a.HW;
 #pragma unroll
             for (int kg = 0; kg < NKG; ++kg) {
                 u32x4 hi, lo;
-                const int cb = stage * 16 * KCH + kg * 8;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) raw[kg][i] = (nv && cb + i < a.C) ? raw[kg][i] : 0.f;
                 pack8_split(raw[kg], hi, lo);
                 s_ah[kg * 256 + tid] = hi;
                 s_al[kg * 256 + tid] = lo;
@@ -240,8 +250,14 @@ hipError_t launch_attn_ctx(const float *x, const unsigned char *wkv, float *part
     a.x = x; a.wkv = wkv; a.partials = partials; a.C = C; a.HW = HW;
     a.nstage = (C + 16 * ATTN_KCH - 1) / (16 * ATTN_KCH);
     a.tiles = g.tiles; a.tps = g.tps; a.nrec = g.nrec; a.nsplit = nsplit; a.B = B;
-    if (nsplit > 1) hipLaunchKernelGGL(attn_ctx_kernel<2>, dim3(g.nslices * 4 * B), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(attn_ctx_kernel<1>, dim3(g.nslices * 4 * B), dim3(256), 0, st, a);
+    const dim3 grid(g.nslices * 4 * B);
+    if (C % 32 == 0) {
+        if (nsplit > 1) hipLaunchKernelGGL((attn_ctx_kernel<2, 1>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_ctx_kernel<1, 1>), grid, dim3(256), 0, st, a);
+    } else {
+        if (nsplit > 1) hipLaunchKernelGGL((attn_ctx_kernel<2, 0>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_ctx_kernel<1, 0>), grid, dim3(256), 0, st, a);
+    }
     return hipGetLastError();
 }
 

@@ -1196,7 +1196,8 @@ extern "C" int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, con
             }
             case OP_GNFIN: s_kernel = "gtts::gn_finalize_kernel"; break;
             case OP_TAILID: s_kernel = "gtts::tail_identity_kernel"; by = 4.0 * B * o.C * Hi * Wi * 3; break;
-            case OP_ACTX: s_kernel = plan->cfg.precision == GTTS_PREC_BF16 ? "gtts::attn_ctx_kernel<1>" : "gtts::attn_ctx_kernel<2>"; fl = 2.0 * B * Hi * Wi * (256.0 * o.C + 128.0 * 32);
+            case OP_ACTX: s_kernel = plan->cfg.precision == GTTS_PREC_BF16 ? (o.C % 32 == 0 ? "gtts::attn_ctx_kernel<1, 1>" : "gtts::attn_ctx_kernel<1, 0>")
+                                                                           : (o.C % 32 == 0 ? "gtts::attn_ctx_kernel<2, 1>" : "gtts::attn_ctx_kernel<2, 0>"); fl = 2.0 * B * Hi * Wi * (256.0 * o.C + 128.0 * 32);
                 by = 4.0 * B * o.C * Hi * Wi; break;
             case OP_AMERGE: s_kernel = "gtts::attn_merge_kernel"; break;
             case OP_INSTATS: s_kernel = "gtts::instnorm_stats_kernel"; by = 4.0 * B * o.C * Hi * Wi; break;
