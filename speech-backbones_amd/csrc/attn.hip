@@ -60,15 +60,16 @@ __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
 
     float raw[NKG][8];
     u32x4 wregs[KCH];
-    // Buffer loads: the lane's pixel is the per-lane byte offset, the channel offset is an SGPR; pixels >= HW get a
-    // per-lane offset past the end of the descriptor and read 0 from the bounds check (which covers the per-lane
-    // offset only, so a channel >= C is clamped and zeroed explicitly -- never the case when C % 32 == 0).
+    // Buffer loads: the lane's pixel is the per-lane byte offset, the channel offset is an SGPR -> no VALU address
+    // arithmetic.  Pixels >= HW get a per-lane offset equal to the descriptor size: the bounds check (which covers the
+    // per-lane offset) returns 0 for them without touching memory.  Channels >= C (only when C % 32 != 0) are
+    // clamped and zeroed by a select, since the scalar offset is not part of the check.
     const unsigned long long xaddr = reinterpret_cast<unsigned long long>(xb);
+    const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xaddr);           // (unsigned: the builtin returns int and
+    const unsigned xhi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));   //  would sign-extend into the high word)
     const int xbytes = a.C * a.HW * 4;
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<void *>(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32)) << 32) |
-                                 __builtin_amdgcn_readfirstlane((unsigned)xaddr)),
-        0, __builtin_amdgcn_readfirstlane(xbytes), 0x00020000);
+        reinterpret_cast<void *>(((unsigned long long)xhi << 32) | xlo), 0, __builtin_amdgcn_readfirstlane(xbytes), 0x00020000);
     auto load = [&](int tile, int stage) {
         const int n = tile * 256 + tid;
         const int voff = n < a.HW ? n * 4 : xbytes;
