@@ -247,6 +247,7 @@ __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
 hipError_t launch_attn_ctx(const float *x, const unsigned char *wkv, float *partials, int B, int C, int HW, int nsplit,
                            hipStream_t st) {
     AttnGeom g = attn_geom(HW);
+    if ((size_t)C * HW * 4 >= ((size_t)1 << 31)) return hipErrorInvalidValue;     // 32-bit offsets in the buffer descriptor
     AttnCtxArgs a;
     a.x = x; a.wkv = wkv; a.partials = partials; a.C = C; a.HW = HW;
     a.nstage = (C + 16 * ATTN_KCH - 1) / (16 * ATTN_KCH);

@@ -25,6 +25,7 @@
 //
 // Wave tile: (MF x 32) output channels x (2 rows x 32 columns) pixels; a workgroup is WM x WN waves.
 #include "common.h"
+#include <algorithm>
 
 // minimum waves per SIMD requested from the register allocator (= workgroups per CU with 4-wave workgroups)
 #ifndef GTTS_C3_WAVES
@@ -559,6 +560,10 @@ static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
     const int ncot = (a.cout + C::MT - 1) / C::MT;
     dim3 grid(a.tiles_x * a.tiles_y * ncot * (MODE == CONV_UP ? 4 : 1) * a.B);
     if (a.cout % C::MT != 0) return hipErrorInvalidValue;   // epilogue assumes whole output-channel tiles
+    // buffer descriptors address one sample's tensor with 32-bit byte offsets
+    const size_t lim = (size_t)1 << 31;
+    const size_t in_c = (size_t)(PRO == PRO_IGLU ? 2 * a.cin : std::max(a.c0, a.c1));
+    if (in_c * a.Hin * a.Win * 4 >= lim || (size_t)a.cout * a.Hout * a.Wout * 4 >= lim) return hipErrorInvalidValue;
     size_t smem = conv_smem_bytes(C::NPIX, C::NKG, C::WBLK16, a.cin, PRO, C::MT);
     static size_t attr_set = 0;
     if (smem > attr_set) {
