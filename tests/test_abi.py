@@ -29,6 +29,28 @@ def test_header_symbols_are_exported():
         assert hasattr(lib, name)
 
 
+def test_cfg_struct_layout_matches_the_header(tmp_path):
+    """The ctypes mirror of gtts_unet_cfg (and the copy in INTEGRATION.md) must have the C compiler's layout of the
+    struct in include/gradtts_abi.h: compile the header with gcc and compare size and every field offset."""
+    S = pkg()
+    fields = [f[0] for f in S._lib.UnetCfg._fields_]
+    prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "gradtts_abi.h"', 'int main(void) {',
+            '  printf("%zu\\n", sizeof(gtts_unet_cfg));']
+    prog += ['  printf("%%zu\\n", offsetof(gtts_unet_cfg, %s));' % f for f in fields]
+    prog += ['  return 0; }']
+    src = tmp_path / "cfg.c"
+    src.write_text("\n".join(prog))
+    exe = tmp_path / "cfg"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    nums = [int(x) for x in subprocess.check_output([str(exe)]).decode().split()]
+    assert nums[0] == ctypes.sizeof(S._lib.UnetCfg)
+    assert nums[1:] == [getattr(S._lib.UnetCfg, f).offset for f in fields]
+    # the binding stub shown to reference maintainers lists the same fields in the same order
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = doc[doc.index("class _Cfg"):doc.index("_L.gtts_packed_weight_bytes.restype")]
+    assert re.findall(r'\("([a-z_]+)", ctypes', stub) == fields
+
+
 def test_plan_layout_and_validation():
     S = pkg()
     from oracle import gradtts_oracle as O
