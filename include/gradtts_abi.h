@@ -133,6 +133,14 @@ size_t gtts_mas_scratch_bytes(int b, int tx, int ty);
 int gtts_mas_maximum_path(const float *value, const float *mask, const int *t_x, const int *t_y, int *path,
                           void *scratch, int b, int tx, int ty, gtts_stream_t stream);
 
+/* ---- pre-decoder glue of GradTTS.forward: generate_path + mu_y = attn^T . mu_x + z  (tts.py:84-94, utils.py:26-39) -
+ * duration [B,t_x] fp32 (= w_ceil incl. length_scale), x_mask [B,t_x] fp32, y_lengths [B] int32 (device),
+ * mu_x [B,F,t_x]; noise [B,F,T] or NULL, temperature; outputs attn [B,t_x,T], mu_y [B,F,T], z [B,F,T] (z may be NULL;
+ * noise NULL gives z = mu_y).  Bit-identical to the reference's CPU path (sequential fp32 cumsum, float compares). */
+int gtts_expand_alignment(const float *duration, const float *x_mask, const int *y_lengths, const float *mu_x,
+                          const float *noise, float temperature, float *attn, float *mu_y, float *z, int B, int F,
+                          int t_x, int T, gtts_stream_t stream);
+
 /* ---- debugging / tests: named intermediates of the last estimator call (keep_intermediates plans) ----- */
 int gtts_plan_num_tensors(const gtts_plan *plan);
 /* offset is in bytes into the workspace for the given (B,T); dims = {B,C,H,W}. */

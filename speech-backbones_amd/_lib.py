@@ -60,6 +60,7 @@ def lib():
         L.gtts_mas_scratch_bytes.argtypes = [i, i, i]
         L.gtts_mas_scratch_bytes.restype = sz
         L.gtts_mas_maximum_path.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, vp]
+        L.gtts_expand_alignment.argtypes = [vp, vp, vp, vp, vp, f, vp, vp, vp, i, i, i, i, vp]
         L.gtts_plan_num_tensors.argtypes = [vp]
         L.gtts_plan_tensor_info.argtypes = [vp, i, i, i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz),
                                             ctypes.POINTER(i * 4)]
@@ -343,3 +344,27 @@ def mas_maximum_path(value, mask):
         _check(lib().gtts_mas_maximum_path(_ptr(v), _ptr(m), _ptr(t_x), _ptr(t_y), _ptr(path), _ptr(scratch), b, tx,
                                            ty, _stream()), "gtts_mas_maximum_path")
     return path.to(dtype=value.dtype)
+
+
+def expand_alignment(duration, x_mask, y_lengths, mu_x, T, noise=None, temperature=1.0):
+    """generate_path + mu_y = attn^T . mu_x + z = mu_y + noise / temperature in one launch (tts.py:84-94).
+
+    duration, x_mask: [B, t_x]; y_lengths: [B] integer; mu_x: [B, F, t_x]; noise: [B, F, T] or None.
+    Returns (attn [B, t_x, T], mu_y [B, F, T], z [B, F, T] or None), bit-identical to the reference's CPU path."""
+    if not mu_x.is_cuda:
+        raise RuntimeError("expand_alignment needs HIP tensors; there is no CPU fallback")
+    d, m, mx = _f32c(duration, "duration"), _f32c(x_mask, "x_mask"), _f32c(mu_x, "mu_x")
+    B, F, tx = mx.shape
+    if d.shape != (B, tx) or m.shape != (B, tx):
+        raise RuntimeError("duration / x_mask must be [B, t_x] = [%d, %d]" % (B, tx))
+    yl = y_lengths.to(device=mx.device, dtype=torch.int32).contiguous()
+    nz = _f32c(noise, "noise")
+    if nz is not None and nz.shape != (B, F, T):
+        raise RuntimeError("noise must be [B, F, T]")
+    attn = torch.empty((B, tx, T), dtype=torch.float32, device=mx.device)
+    mu_y = torch.empty((B, F, T), dtype=torch.float32, device=mx.device)
+    z = torch.empty((B, F, T), dtype=torch.float32, device=mx.device) if nz is not None else None
+    with torch.cuda.device(mx.device):
+        _check(lib().gtts_expand_alignment(_ptr(d), _ptr(m), _ptr(yl), _ptr(mx), _ptr(nz), float(temperature), _ptr(attn),
+                                           _ptr(mu_y), _ptr(z), B, F, tx, int(T), _stream()), "gtts_expand_alignment")
+    return attn, mu_y, z

@@ -94,6 +94,11 @@ hipError_t launch_pack_conv(int mode, const float *w, unsigned char *dst, int ci
 hipError_t launch_pack_attn_kv(const float *wqkv, unsigned char *dst, int C, hipStream_t st);
 hipError_t launch_copy_f32(const float *src, float *dst, size_t n, hipStream_t st);
 
+// ---- glue.hip (generate_path + aligned prior mean + terminal sample: tts.py:84-94, utils.py:26-39)
+hipError_t launch_expand_alignment(const float *dur, const float *x_mask, const int *y_len, const float *mu_x,
+                                   const float *noise, float temperature, float *attn, float *mu_y, float *z, int B, int F,
+                                   int tx, int T, hipStream_t st);
+
 // ---- mas.hip
 hipError_t launch_mas(const float *value, const float *mask, const int *t_x, const int *t_y, int *path,
                       unsigned char *scratch, int b, int tx, int ty, hipStream_t st);

@@ -1145,6 +1145,19 @@ extern "C" int gtts_mas_maximum_path(const float *value, const float *mask, cons
 }
 
 
+extern "C" int gtts_expand_alignment(const float *duration, const float *x_mask, const int *y_lengths, const float *mu_x,
+                                     const float *noise, float temperature, float *attn, float *mu_y, float *z, int B, int F,
+                                     int t_x, int T, gtts_stream_t stream) {
+    if (!duration || !x_mask || !y_lengths || !mu_x || !attn || !mu_y) return fail(GTTS_E_NULL, "gtts_expand_alignment: null argument");
+    if (B <= 0 || F <= 0 || t_x <= 0 || T <= 0) return fail(GTTS_E_SHAPE, "gtts_expand_alignment: bad shape B=%d F=%d t_x=%d T=%d", B, F, t_x, T);
+    if (noise && !(temperature > 0.f)) return fail(GTTS_E_SHAPE, "gtts_expand_alignment: temperature must be positive");
+    if (((size_t)t_x + T) * 4 > 160 * 1024) return fail(GTTS_E_SHAPE, "t_x + T too large for the LDS tables (%d + %d)", t_x, T);
+    HIPCHK(launch_expand_alignment(duration, x_mask, y_lengths, mu_x, noise, temperature, attn, mu_y, z, B, F, t_x, T,
+                                   (hipStream_t)stream));
+    return GTTS_OK;
+}
+
+
 // ------------------------------------------------------------------------------------------------ measurement
 static std::string conv_kernel_name(int mode, int cin, int cout, int pro, int epi, int nsplit) {
     const bool wide = cout > 64;

@@ -7,6 +7,7 @@ import random
 import torch
 
 from . import monotonic_align
+from ._backend import backend
 from .base import BaseModule
 from .diffusion import Diffusion
 from .text_encoder import TextEncoder
@@ -48,15 +49,23 @@ class GradTTS(BaseModule):
         y_max_length = int(y_lengths.max())
         y_max_length_ = fix_len_compatibility(y_max_length)
 
-        # alignment path from durations (tts.py:84-86) and aligned prior mean (tts.py:89-91)
+        # alignment path from durations (tts.py:84-86), aligned prior mean (tts.py:89-91) and terminal sample (tts.py:94)
         y_mask = sequence_mask(y_lengths, y_max_length_).unsqueeze(1).to(x_mask.dtype)
-        attn_mask = x_mask.unsqueeze(-1) * y_mask.unsqueeze(2)
-        attn = generate_path(w_ceil.squeeze(1), attn_mask.squeeze(1)).unsqueeze(1)
-        mu_y = torch.matmul(attn.squeeze(1).transpose(1, 2), mu_x.transpose(1, 2)).transpose(1, 2)
+        if mu_x.is_cuda and not torch.is_grad_enabled():
+            # one HIP launch instead of the dense [B,t_x,T] path and its matmul.  The reference draws
+            # randn_like(mu_y) on a transposed [B,T,80] buffer; the same strides keep the Philox stream -> element map.
+            tmpl = torch.empty(mu_x.shape[0], y_max_length_, mu_x.shape[1], dtype=mu_x.dtype, device=mu_x.device)
+            noise = torch.randn_like(tmpl.transpose(1, 2), device=mu_x.device)
+            attn, mu_y, z = backend().expand_alignment(w_ceil.squeeze(1), x_mask.squeeze(1), y_lengths, mu_x, y_max_length_,
+                                                      noise, temperature)
+            attn = attn.unsqueeze(1)
+        else:
+            attn_mask = x_mask.unsqueeze(-1) * y_mask.unsqueeze(2)
+            attn = generate_path(w_ceil.squeeze(1), attn_mask.squeeze(1)).unsqueeze(1)
+            mu_y = torch.matmul(attn.squeeze(1).transpose(1, 2), mu_x.transpose(1, 2)).transpose(1, 2)
+            z = mu_y + torch.randn_like(mu_y, device=mu_y.device) / temperature
         encoder_outputs = mu_y[:, :, :y_max_length]
 
-        # terminal sample and reverse diffusion (tts.py:94-97)
-        z = mu_y + torch.randn_like(mu_y, device=mu_y.device) / temperature
         decoder_outputs = self.decoder(z, y_mask, mu_y, n_timesteps, stoc, spk)[:, :, :y_max_length]
         # reference quirk kept (tts.py:99): the slice below indexes the t_x axis of attn [B,1,t_x,T]
         return encoder_outputs, decoder_outputs, attn[:, :, :y_max_length]

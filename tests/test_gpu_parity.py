@@ -307,6 +307,8 @@ def test_gradtts_forward_drop_in(S, dev):
     path = O.generate_path(w_ceil.squeeze(1), attn_mask.squeeze(1)).unsqueeze(1)
     assert torch.equal(attn.cpu(), path[:, :, :y_max])                  # bit-exact alignment (+ t_x-axis slice quirk)
     mu_y = torch.matmul(path.squeeze(1).transpose(1, 2), mu_x.cpu().transpose(1, 2)).transpose(1, 2)
+    # (mu_x is re-derived by a second encoder pass, which need not be bit-identical to the first; the gather itself
+    # is checked bit-exactly in test_expand_alignment_bit_exact)
     assert relerr(enc.cpu(), mu_y[:, :, :y_max]) <= 1e-5
     torch.manual_seed(77)
     # tts.py:94 draws randn_like(mu_y) where mu_y is a transposed (non-contiguous) [B,T,80] buffer: the Philox
@@ -316,6 +318,32 @@ def test_gradtts_forward_drop_in(S, dev):
     ref = O.reverse_diffusion(sd, z, y_mask, mu_y, 4)[:, :, :y_max]
     assert dec_out.shape == ref.shape
     assert relerr(dec_out.cpu(), ref) <= REL
+
+
+def test_expand_alignment_bit_exact(S, dev):
+    """gtts_expand_alignment (generate_path + attn^T.mu_x + z, tts.py:84-94 / utils.py:26-39) against the oracle on CPU:
+    ragged utterances, non-integer length_scale (the cumsum order matters), masked tokens, frames past y_length."""
+    g = torch.Generator().manual_seed(11)
+    B, F, tx = 5, 80, 37
+    xl = torch.tensor([37, 20, 1, 29, 8])
+    x_mask = O.sequence_mask(xl, tx).float()
+    for length_scale in (1.0, 0.91, 1.37):
+        w_ceil = torch.ceil(torch.rand(B, tx, generator=g) * 6.0 * x_mask) * length_scale
+        y_lengths = torch.clamp_min(w_ceil.sum(1), 1).long()
+        T = O.fix_len_compatibility(int(y_lengths.max()))
+        y_mask = O.sequence_mask(y_lengths, T).float()
+        mu_x = torch.randn(B, F, tx, generator=g)
+        noise = torch.randn(B, F, T, generator=g)
+        path = O.generate_path(w_ceil, x_mask.unsqueeze(-1) * y_mask.unsqueeze(1))
+        mu_y = torch.matmul(path.transpose(1, 2), mu_x.transpose(1, 2)).transpose(1, 2)
+        z = mu_y + noise / 1.5
+        attn, my, zz = S._lib.expand_alignment(w_ceil.to(dev), x_mask.to(dev), y_lengths.to(dev), mu_x.to(dev), T,
+                                               noise.to(dev), 1.5)
+        assert torch.equal(attn.cpu(), path)
+        assert torch.equal(my.cpu(), mu_y)
+        assert torch.equal(zz.cpu(), z)
+    with pytest.raises(RuntimeError):
+        S._lib.expand_alignment(w_ceil, x_mask, y_lengths, mu_x, T)          # CPU tensors: no fallback
 
 
 def test_monotonic_align_module_on_gpu(S, dev):
