@@ -42,6 +42,15 @@
 // GTTS_TRACE=1 (diagnostic builds only): per-wave s_memtime phase sums of the 3x3 GroupNorm kernel, read back with
 // gtts_debug_trace().  Phases: 0 top-of-chunk barrier, 1 activation transform + LDS write, 2 weight wait + LDS write,
 // 3 barrier after the weight write, 4 prefetch issue + fragment reads + MFMAs, 5 inter-stage barrier, 6 whole loop.
+// GTTS_WDMA=1: where LDS allows two weight-stage buffers at three workgroups per CU (the 64-cout tile of the 3x3
+// conv), the packed weight stage goes global -> LDS directly (buffer_load_dwordx4 ... lds): no staging VGPRs, no
+// ds_write_b128, and -- the stage being double-buffered -- one barrier per weight stage instead of two.  Verified
+// correct on MI355X (all parity tests) and speed-neutral (214.6 vs 215.9 us): waits and barriers of one wave are
+// covered by the other two waves of the SIMD; what adds to the MFMA time is VALU work, which this does not change.
+// Off by default (it costs 12 KB of LDS); kept as the building block for DMA-staged activations.
+#ifndef GTTS_WDMA
+#define GTTS_WDMA 0
+#endif
 #ifndef GTTS_TRACE
 #define GTTS_TRACE 0
 #endif
@@ -79,6 +88,9 @@ struct ConvCfg {
 };
 
 static inline int conv_npar(int pro) { return pro == PRO_GN ? 3 : (pro == PRO_IGLU ? 5 : 0); }
+template <int MODE, int WM, int FULLC>
+struct ConvWdma { static constexpr bool on = GTTS_WDMA && !GTTS_TRACE && GTTS_EXP == 0 && MODE == CONV_C3 && WM == 1 && FULLC; };
+
 static inline size_t conv_smem_bytes(int npix, int nkg, int wblk16, int cin, int pro, int mt) {
     size_t cpad = (size_t)((cin + 8 * nkg - 1) / (8 * nkg)) * 8 * nkg;
     return (size_t)npix * nkg * 16 * 2 + (size_t)wblk16 * 16 + (size_t)conv_npar(pro) * cpad * 4 + 4 * 2 * 4 * 2 * 4 +
@@ -101,10 +113,11 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4 *s_ah = reinterpret_cast<u32x4 *>(smem);      // [NKG][NPIX]  hi
     u32x4 *s_al = s_ah + NKG * NPIX;                    // [NKG][NPIX]  lo
-    u32x4 *s_w = s_al + NKG * NPIX;                     // [split][tap][kg][MT]
+    constexpr bool WDMA = ConvWdma<MODE, WM, FULLC>::on;
+    u32x4 *s_w = s_al + NKG * NPIX;                     // [split][tap][kg][MT]  (WDMA: two such buffers)
     const int cpad = a.nchunk * 8 * NKG;
     // PRO_GN: [3][cpad] scale, shift, time bias; PRO_IGLU: [5][cpad] scale_a, shift_a, time bias, scale_b, shift_b
-    float *s_par = reinterpret_cast<float *>(s_w + WBLK16);
+    float *s_par = reinterpret_cast<float *>(s_w + (WDMA ? 2 : 1) * WBLK16);
     constexpr int NPAR = PRO == PRO_GN ? 3 : (PRO == PRO_IGLU ? 5 : 0);
     float *s_red = s_par + NPAR * cpad;                       // [4 waves][MF][4 octets][2]
     float *s_epi = s_red + 4 * 2 * 4 * 2;                     // [3][MT]: bias, (EPI_TAIL) GN scale, shift
@@ -212,9 +225,18 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
     const __amdgpu_buffer_rsrc_t rsw = uniform_rsrc(wbase, wtotal);
     auto load_w = [&](int chunk, int stage) {
         const int blk = ((phase * a.nchunk + chunk) * NST + stage) * ncot + cot;
+        if constexpr (WDMA) {
+            // straight into LDS buffer (global stage index & 1): lane l of a wave lands at the wave's base + 16 l
+            u32x4 *dst = s_w + ((chunk * NST + stage) & 1) * WBLK16 + wave * 64;
 #pragma unroll
-        for (int i = 0; i < WITER; ++i)
-            wregs[i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (tid + i * 256) * 16, blk * (WBLK16 * 16), 0);
+            for (int i = 0; i < WITER; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void *)(dst + i * 256), 16,
+                                                         (tid + i * 256) * 16, blk * (WBLK16 * 16), 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < WITER; ++i)
+                wregs[i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (tid + i * 256) * 16, blk * (WBLK16 * 16), 0);
+        }
     };
 
     f32x16 acc[MF][2];
@@ -343,12 +365,22 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
         TR_MARK(1);
 #pragma unroll
         for (int stage = 0; stage < NST; ++stage) {
-            if (stage > 0) { GTTS_SYNC(); TR_MARK(5); }   // previous stage's MFMAs are done with s_w
+            const u32x4 *s_wc = s_w;                        // weight buffer read by this stage's MFMAs
+            if constexpr (WDMA) {
+                // this stage's weights were DMA'd during the previous stage; every wave waits for its own pieces
+                // (and, conservatively, every other load in flight) and the barrier publishes them -- and, at
+                // stage 0, the activation image written above.  The same barrier frees the other buffer.
+                __builtin_amdgcn_s_waitcnt(0x0f70);         // vmcnt(0)
+                GTTS_SYNC();
+                s_wc = s_w + ((chunk * NST + stage) & 1) * WBLK16;
+            } else {
+                if (stage > 0) { GTTS_SYNC(); TR_MARK(5); }   // previous stage's MFMAs are done with s_w
 #pragma unroll
-            for (int i = 0; i < (GTTS_EXP == 4 ? 0 : WITER); ++i) s_w[tid + i * 256] = wregs[i];
-            TR_MARK(2);
-            GTTS_SYNC();
-            TR_MARK(3);
+                for (int i = 0; i < (GTTS_EXP == 4 ? 0 : WITER); ++i) s_w[tid + i * 256] = wregs[i];
+                TR_MARK(2);
+                GTTS_SYNC();
+                TR_MARK(3);
+            }
             // ---- prefetch behind the MFMAs: next weight block (one stage ahead) and, as early as the staging
             // registers are free again, the next activation chunk (a whole chunk of MFMAs ahead)
             if (GTTS_EXP == 4) {
@@ -380,8 +412,8 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
 #pragma unroll
                     for (int mi = 0; mi < MF; ++mi) {
                         int wi = (j * NKG + kc * 2 + kg_l) * MT + m0 + mi * 32 + l31;
-                        wh[mi] = *reinterpret_cast<const bf16x8 *>(&s_w[wi]);
-                        if (NSPLIT > 1) wl[mi] = *reinterpret_cast<const bf16x8 *>(&s_w[wi + TPS * NKG * MT]);
+                        wh[mi] = *reinterpret_cast<const bf16x8 *>(&s_wc[wi]);
+                        if (NSPLIT > 1) wl[mi] = *reinterpret_cast<const bf16x8 *>(&s_wc[wi + TPS * NKG * MT]);
                     }
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni) {
@@ -564,7 +596,8 @@ static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
     const size_t lim = (size_t)1 << 31;
     const size_t in_c = (size_t)(PRO == PRO_IGLU ? 2 * a.cin : std::max(a.c0, a.c1));
     if (in_c * a.Hin * a.Win * 4 >= lim || (size_t)a.cout * a.Hout * a.Wout * 4 >= lim) return hipErrorInvalidValue;
-    size_t smem = conv_smem_bytes(C::NPIX, C::NKG, C::WBLK16, a.cin, PRO, C::MT);
+    size_t smem = conv_smem_bytes(C::NPIX, C::NKG, C::WBLK16, a.cin, PRO, C::MT) +
+                  (ConvWdma<MODE, WM, FULLC>::on ? (size_t)C::WBLK16 * 16 : 0);
     static size_t attr_set = 0;
     if (smem > attr_set) {
         hipError_t e = hipFuncSetAttribute(
