@@ -11,7 +11,14 @@
  *     reference's own layouts ([B,80,T] mels, [B,1,T] masks flattened to [B,T], NCHW inside).
  *   - the CALLER owns every device buffer (inputs, outputs, packed weights, workspace); the library never
  *     allocates device memory and keeps no device pointer after a call returns.
- *   - every call enqueues on the given hipStream_t and returns without synchronising.
+ *   - every call enqueues on the given hipStream_t and returns without synchronising.  The sampler may fan sub-batches
+ *     out onto side streams, but only onto streams the CALLER registered with gtts_plan_set_streams (they are forked
+ *     from and joined back into the call's stream inside the call, also on error paths).
+ *   - a plan is host-side metadata.  Query functions take `const gtts_plan *` and touch nothing; the enqueueing
+ *     functions take `gtts_plan *` and serialise on a mutex inside the plan for the duration of the host-side enqueue,
+ *     so a plan may be shared by host threads as long as every call brings its own workspace.
+ *   - no environment variable changes results; diagnostics (op skipping, phase traces, timing ablations) exist only in
+ *     -DGTTS_DIAG builds, never in the product library.
  *   - every function returns 0 on success or a negative GTTS_E_* code; gtts_last_error() gives the text
  *     (thread-local).  No C++ exception crosses the boundary.
  *   - T (frames) must be a multiple of 4 (Grad-TTS/model/utils.py:13-17 fix_len_compatibility), n_feats a
@@ -27,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GTTS_ABI_VERSION 1
+#define GTTS_ABI_VERSION 2
 
 enum {
     GTTS_OK = 0,
@@ -84,7 +91,14 @@ int gtts_plan_num_params(const gtts_plan *plan);
 int gtts_plan_param_info(const gtts_plan *plan, int i, const char **name, int *rank, int dims[4]);
 
 size_t gtts_packed_weight_bytes(const gtts_plan *plan);
+/* Workspace for gtts_estimator_forward / gtts_reverse_diffusion at (B,T); depends on the number of registered side
+ * streams (each sub-batch works in its own slice), so query it AFTER gtts_plan_set_streams. */
 size_t gtts_workspace_bytes(const gtts_plan *plan, int B, int T);
+
+/* Register n in {0, 2, 3, 4} caller-owned side streams (hipStream_t) on which gtts_reverse_diffusion runs sub-batches
+ * of the utterance batch side by side (bit-identical results; utterances are independent).  n = 0 (default): everything
+ * runs on the stream passed to the call.  The streams must outlive the plan or be unregistered (n = 0) first. */
+int gtts_plan_set_streams(gtts_plan *plan, const gtts_stream_t *streams, int n);
 
 /* Re-layout the estimator parameters (device fp32 pointers, in gtts_plan_param_info order) into the packed
  * blob the kernels read (bf16 hi/lo MFMA fragment order for conv weights, fp32 for the rest).
@@ -95,7 +109,7 @@ int gtts_pack_weights(const gtts_plan *plan, const void *const *param_ptrs, int 
 
 /* ---- GradLogPEstimator2d.forward(x, mask, mu, t, spk)  diffusion.py:174-216 -------------------------- */
 /* x, mu, out [B,F,T]; mask [B,T]; t [B]; spk [B,spk_emb_dim] (already embedded) or NULL. */
-int gtts_estimator_forward(const gtts_plan *plan, const void *packed, const float *x, const float *mask,
+int gtts_estimator_forward(gtts_plan *plan, const void *packed, const float *x, const float *mask,
                            const float *mu, const float *t, const float *spk, float *out, void *workspace,
                            size_t workspace_bytes, int B, int T, gtts_stream_t stream);
 
@@ -105,26 +119,31 @@ int gtts_euler_step(float *xt, const float *mu, const float *est, const float *m
                     float beta_t, float h, int B, int F, int T, gtts_stream_t stream);
 
 /* ---- Diffusion.reverse_diffusion / forward  diffusion.py:254-279 (whole N-step loop) ------------------ */
-/* z, mu, out [B,F,T]; mask [B,T]; spk nullable; noise nullable [N,B,F,T] (stoc=True <=> noise != NULL). */
-int gtts_reverse_diffusion(const gtts_plan *plan, const void *packed, const float *z, const float *mask,
+/* z, mu, out [B,F,T]; mask [B,T]; spk nullable.  Runs steps [step_begin, step_end) of the n_timesteps-step schedule:
+ * step_begin == 0 first sets out = z * mask, later ranges continue in place on `out`, so a host can draw the SDE noise
+ * in bounded chunks.  noise nullable [step_end - step_begin, B,F,T] (stoc=True <=> noise != NULL). */
+int gtts_reverse_diffusion(gtts_plan *plan, const void *packed, const float *z, const float *mask,
                            const float *mu, const float *spk, const float *noise, float *out, void *workspace,
-                           size_t workspace_bytes, int B, int T, int n_timesteps, gtts_stream_t stream);
+                           size_t workspace_bytes, int B, int T, int n_timesteps, int step_begin, int step_end,
+                           gtts_stream_t stream);
 
 /* ---- DiffVC: GradLogPEstimator.forward(x, x_mask, mean, ref, ref_mask, c, t)  DiffVC/model/diffusion.py:61-106 -- */
 /* x, mean, out [B,F,T]; x_mask [B,T]; xt_ref [B,1,F,T_ref] (the diffused reference, diffusion.py:173-176);
  * ref_mask [B,T_ref]; c [B,c_dim]; t [B].  T % 4 == 0; T_ref is free. */
 size_t gtts_vc_workspace_bytes(const gtts_plan *plan, int B, int T, int T_ref);
-int gtts_vc_estimator_forward(const gtts_plan *plan, const void *packed, const float *x, const float *x_mask,
+int gtts_vc_estimator_forward(gtts_plan *plan, const void *packed, const float *x, const float *x_mask,
                               const float *mean, const float *xt_ref, const float *ref_mask, const float *c, const float *t,
                               float *out, void *workspace, size_t workspace_bytes, int B, int T, int T_ref,
                               gtts_stream_t stream);
 /* ---- DiffVC: Diffusion.reverse_diffusion / forward  DiffVC/model/diffusion.py:164-205 ------------------------ */
-/* mode 0 'pf', 1 'em', 2 'ml'; noise [N,B,F,T] pre-drawn N(0,1) (required for em / ml, ignored for pf);
- * ref, mean_ref [B,F,T_ref].  The schedule scalars (beta, gamma, mu, nu, sigma, kappa, omega) are host doubles. */
-int gtts_vc_reverse_diffusion(const gtts_plan *plan, const void *packed, const float *z, const float *mask,
+/* mode 0 'pf', 1 'em', 2 'ml'; steps [step_begin, step_end) as in gtts_reverse_diffusion; noise
+ * [step_end - step_begin, B,F,T] pre-drawn N(0,1) (required for em / ml, ignored for pf); ref, mean_ref [B,F,T_ref].
+ * The schedule scalars (beta, gamma, mu, nu, sigma, kappa, omega) are host doubles. */
+int gtts_vc_reverse_diffusion(gtts_plan *plan, const void *packed, const float *z, const float *mask,
                               const float *mean, const float *ref, const float *ref_mask, const float *mean_ref,
                               const float *c, const float *noise, float *out, void *workspace, size_t workspace_bytes, int B,
-                              int T, int T_ref, int n_timesteps, int mode, gtts_stream_t stream);
+                              int T, int T_ref, int n_timesteps, int mode, int step_begin, int step_end,
+                              gtts_stream_t stream);
 
 /* ---- monotonic_align.maximum_path  monotonic_align/core.pyx:9-45 + __init__.py:8-23 ------------------- */
 /* value [b,tx,ty] fp32 (NOT modified), mask [b,tx,ty] fp32 or NULL, t_x / t_y [b] int32 device arrays,
@@ -132,6 +151,15 @@ int gtts_vc_reverse_diffusion(const gtts_plan *plan, const void *packed, const f
 size_t gtts_mas_scratch_bytes(int b, int tx, int ty);
 int gtts_mas_maximum_path(const float *value, const float *mask, const int *t_x, const int *t_y, int *path,
                           void *scratch, int b, int tx, int ty, gtts_stream_t stream);
+
+/* CPU twin (host pointers, no stream): the reference's maximum_path accepts tensors on any device and runs its Cython
+ * kernel on the host (__init__.py:8-23); bit-identical to the GPU kernel and to core.pyx. */
+int gtts_mas_maximum_path_cpu(const float *value, const float *mask, const int *t_x, const int *t_y, int *path, int b,
+                              int tx, int ty);
+
+/* ---- multi-GPU: the single collective -- RCCL broadcast of the packed weight blob from `root` over xGMI.
+ * comm = the caller's ncclComm_t.  RCCL is resolved from the running process at call time (no link-time dependency). */
+int gtts_bcast_weights(void *packed, size_t bytes, int root, void *comm, gtts_stream_t stream);
 
 /* ---- pre-decoder glue of GradTTS.forward: generate_path + mu_y = attn^T . mu_x + z  (tts.py:84-94, utils.py:26-39) -
  * duration [B,t_x] fp32 (= w_ceil incl. length_scale), x_mask [B,t_x] fp32, y_lengths [B] int32 (device),

@@ -53,10 +53,13 @@ def lib():
         L.gtts_packed_weight_bytes.restype = sz
         L.gtts_workspace_bytes.argtypes = [vp, i, i]
         L.gtts_workspace_bytes.restype = sz
+        L.gtts_plan_set_streams.argtypes = [vp, ctypes.POINTER(vp), i]
+        L.gtts_mas_maximum_path_cpu.argtypes = [vp, vp, vp, vp, vp, i, i, i]
+        L.gtts_bcast_weights.argtypes = [vp, sz, i, vp, vp]
         L.gtts_pack_weights.argtypes = [vp, ctypes.POINTER(vp), i, vp, vp, vp]
         L.gtts_estimator_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, vp]
         L.gtts_euler_step.argtypes = [vp, vp, vp, vp, vp, f, f, i, i, i, vp]
-        L.gtts_reverse_diffusion.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, i, vp]
+        L.gtts_reverse_diffusion.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, i, i, i, vp]
         L.gtts_mas_scratch_bytes.argtypes = [i, i, i]
         L.gtts_mas_scratch_bytes.restype = sz
         L.gtts_mas_maximum_path.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, vp]
@@ -67,7 +70,7 @@ def lib():
         L.gtts_vc_workspace_bytes.argtypes = [vp, i, i, i]
         L.gtts_vc_workspace_bytes.restype = sz
         L.gtts_vc_estimator_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, i, vp]
-        L.gtts_vc_reverse_diffusion.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, i, i, i, vp]
+        L.gtts_vc_reverse_diffusion.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, i, i, i, i, i, vp]
         L.gtts_vc_tensor_info.argtypes = [vp, i, i, i, i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz),
                                           ctypes.POINTER(i * 4)]
         L.gtts_plan_num_ops.argtypes = [vp]
@@ -75,7 +78,7 @@ def lib():
                                         ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         L.gtts_profile_enable.argtypes = [vp, i]
         L.gtts_profile_collect.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]
-        if L.gtts_abi_version() != 1:
+        if L.gtts_abi_version() != 2:
             raise RuntimeError("libgradtts_gfx950.so ABI version mismatch")
         _lib = L
         return _lib
@@ -110,14 +113,45 @@ class Plan:
 
     def __init__(self, dim=64, n_feats=80, n_spks=1, spk_emb_dim=64, groups=8, pe_scale=1000.0, beta_min=0.05,
                  beta_max=20.0, precision=PREC_BF16X3, keep_intermediates=False, arch=0, dim_cond=128, use_ref_t=True,
-                 c_dim=256):
-        """arch=0: Grad-TTS GradLogPEstimator2d; arch=1: DiffVC GradLogPEstimator (dim = dim_base)."""
+                 c_dim=256, streams=None):
+        """arch=0: Grad-TTS GradLogPEstimator2d; arch=1: DiffVC GradLogPEstimator (dim = dim_base).
+
+        streams: number of sub-batches gtts_reverse_diffusion runs side by side on torch side streams owned by this
+        object and registered with gtts_plan_set_streams (0 / 1: no split; default 3, or $GTTS_STREAMS)."""
+        self._kw = dict(dim=dim, n_feats=n_feats, n_spks=n_spks, spk_emb_dim=spk_emb_dim, groups=groups,
+                        pe_scale=pe_scale, beta_min=beta_min, beta_max=beta_max, precision=precision,
+                        keep_intermediates=keep_intermediates, arch=arch, dim_cond=dim_cond, use_ref_t=use_ref_t,
+                        c_dim=c_dim, streams=streams)
         self.cfg = UnetCfg(int(dim), int(n_feats), int(n_spks), int(spk_emb_dim), int(groups), float(pe_scale),
                            float(beta_min), float(beta_max), int(precision), 1 if keep_intermediates else 0, int(arch),
                            int(dim_cond), 1 if use_ref_t else 0, int(c_dim), float(beta_min), float(beta_max))
         self._h = ctypes.c_void_p()
         _check(lib().gtts_plan_create(ctypes.byref(self.cfg), ctypes.byref(self._h)), "gtts_plan_create")
         self._ws = {}
+        if streams is None:
+            streams = int(os.environ.get("GTTS_STREAMS", "3"))
+        self._nstreams = 0 if int(streams) < 2 else min(int(streams), 4)
+        self._side = None           # (device, [torch.cuda.Stream])
+
+    # a Plan is host metadata: copies / pickles rebuild it from its constructor arguments (EMA deep copies,
+    # torch.save(model) of a module that already sampled)
+    def __reduce__(self):
+        return (_rebuild_plan, (self._kw,))
+
+    def __deepcopy__(self, memo):
+        return Plan(**self._kw)
+
+    def _use_streams(self, device):
+        """Register this plan's side streams for `device` (created once; they belong to this object)."""
+        if self._nstreams < 2:
+            return
+        if self._side is not None and self._side[0] == device:
+            return
+        side = [torch.cuda.Stream(device=device) for _ in range(self._nstreams)]
+        arr = (ctypes.c_void_p * len(side))(*[s.cuda_stream for s in side])
+        _check(lib().gtts_plan_set_streams(self._h, arr, len(side)), "gtts_plan_set_streams")
+        self._side = (device, side)
+        self._ws.clear()            # the workspace size depends on the number of sub-batches
 
     def __del__(self):
         try:
@@ -210,11 +244,12 @@ class Plan:
         if noise is not None and tuple(noise.shape) != (int(n_timesteps), B, F, T):
             raise RuntimeError("noise must be [n_timesteps, B, F, T]")
         out = torch.empty_like(z)
+        self._use_streams(z.device)
         ws = self.workspace(B, T, z.device)
         with torch.cuda.device(z.device):
             _check(lib().gtts_reverse_diffusion(self._h, _ptr(blob), _ptr(z), _ptr(mask), _ptr(mu), _ptr(spk),
                                                 _ptr(noise), _ptr(out), _ptr(ws), ws.numel(), B, T, int(n_timesteps),
-                                                _stream()), "gtts_reverse_diffusion")
+                                                0, int(n_timesteps), _stream()), "gtts_reverse_diffusion")
         return out
 
     # ---- DiffVC (arch=1)
@@ -244,25 +279,43 @@ class Plan:
                                                    _stream()), "gtts_vc_estimator_forward")
         return out
 
-    def vc_reverse_diffusion(self, blob, z, mask, mean, ref, ref_mask, mean_ref, c, n_timesteps, mode, noise=None):
-        """DiffVC Diffusion.reverse_diffusion (DiffVC/model/diffusion.py:164-196); mode in {'pf','em','ml'}."""
+    def vc_reverse_diffusion(self, blob, z, mask, mean, ref, ref_mask, mean_ref, c, n_timesteps, mode, noise=None,
+                             noise_chunk_bytes=256 << 20):
+        """DiffVC Diffusion.reverse_diffusion (DiffVC/model/diffusion.py:164-196); mode in {'pf','em','ml'}.
+
+        noise (em / ml): a [n_timesteps, B, F, T] tensor, or a callable `draw(k)` returning the next k steps' N(0,1)
+        draws as [k, B, F, T] -- then the loop runs in step ranges of at most noise_chunk_bytes of noise, so long
+        schedules never hold more than one chunk (the reference holds one [B,F,T] draw at a time)."""
         modes = {"pf": 0, "em": 1, "ml": 2}
         if mode not in modes:
             raise RuntimeError("mode must be one of pf / em / ml")
-        z, mask, mean, ref, ref_mask, mean_ref, c, noise = (_f32c(v, n) for v, n in (
-            (z, "z"), (mask, "mask"), (mean, "mean"), (ref, "ref"), (ref_mask, "ref_mask"), (mean_ref, "mean_ref"), (c, "c"),
-            (noise, "noise")))
+        draw = noise if callable(noise) else None
+        z, mask, mean, ref, ref_mask, mean_ref, c = (_f32c(v, n) for v, n in (
+            (z, "z"), (mask, "mask"), (mean, "mean"), (ref, "ref"), (ref_mask, "ref_mask"), (mean_ref, "mean_ref"), (c, "c")))
         B, F, T = z.shape
+        N = int(n_timesteps)
         Tr = int(ref_mask.shape[-1]) if ref_mask is not None else T
-        if mode != "pf" and (noise is None or tuple(noise.shape) != (int(n_timesteps), B, F, T)):
-            raise RuntimeError("em / ml sampling needs noise of shape [n_timesteps, B, F, T]")
+        if draw is None:
+            noise = _f32c(noise, "noise")
+            if mode != "pf" and (noise is None or tuple(noise.shape) != (N, B, F, T)):
+                raise RuntimeError("em / ml sampling needs noise of shape [n_timesteps, B, F, T] (or a callable)")
         out = torch.empty_like(z)
         ws = self.vc_workspace(B, T, Tr, z.device)
+        per = max(1, int(noise_chunk_bytes) // max(1, B * F * T * 4)) if (draw is not None and mode != "pf") else N
         with torch.cuda.device(z.device):
-            _check(lib().gtts_vc_reverse_diffusion(self._h, _ptr(blob), _ptr(z), _ptr(mask), _ptr(mean), _ptr(ref),
-                                                   _ptr(ref_mask), _ptr(mean_ref), _ptr(c), _ptr(noise), _ptr(out), _ptr(ws),
-                                                   ws.numel(), B, T, Tr, int(n_timesteps), modes[mode], _stream()),
-                   "gtts_vc_reverse_diffusion")
+            i0 = 0
+            while i0 < N:
+                i1 = min(N, i0 + per)
+                nz = None
+                if mode != "pf":
+                    nz = _f32c(draw(i1 - i0), "noise") if draw is not None else noise[i0:i1]
+                    if tuple(nz.shape) != (i1 - i0, B, F, T):
+                        raise RuntimeError("noise chunk must be [%d, B, F, T]" % (i1 - i0))
+                _check(lib().gtts_vc_reverse_diffusion(self._h, _ptr(blob), _ptr(z), _ptr(mask), _ptr(mean), _ptr(ref),
+                                                       _ptr(ref_mask), _ptr(mean_ref), _ptr(c), _ptr(nz), _ptr(out), _ptr(ws),
+                                                       ws.numel(), B, T, Tr, N, modes[mode], i0, i1, _stream()),
+                       "gtts_vc_reverse_diffusion")
+                i0 = i1
         return out
 
     def vc_tensors(self, B, T, Tr, device):
@@ -317,6 +370,10 @@ class Plan:
         return out
 
 
+def _rebuild_plan(kw):
+    return Plan(**kw)
+
+
 def euler_step(xt, mu, est, mask, beta_t, h, noise=None):
     """In-place update of xt (one step of Diffusion.reverse_diffusion, diffusion.py:264-274)."""
     if not xt.is_cuda or xt.dtype != torch.float32 or not xt.is_contiguous():
@@ -330,9 +387,21 @@ def euler_step(xt, mu, est, mask, beta_t, h, noise=None):
 
 
 def mas_maximum_path(value, mask):
-    """monotonic_align.maximum_path(value, mask) on the GPU (value, mask: [b, t_x, t_y] HIP tensors)."""
+    """monotonic_align.maximum_path(value, mask) (value, mask: [b, t_x, t_y]).
+
+    HIP tensors run the GPU kernel.  Host tensors run the library's C++ twin gtts_mas_maximum_path_cpu -- the
+    reference's wrapper accepts tensors on any device and always runs its Cython kernel on the host
+    (monotonic_align/__init__.py:8-23); both are bit-identical to it."""
     if not value.is_cuda:
-        raise RuntimeError("value must live on a HIP device; the GPU MAS kernel has no CPU fallback")
+        v = value.detach().float().contiguous()
+        m = mask.detach().to(dtype=torch.float32).contiguous()
+        b, tx, ty = v.shape
+        t_x = m.sum(1)[:, 0].to(torch.int32).contiguous()
+        t_y = m.sum(2)[:, 0].to(torch.int32).contiguous()
+        path = torch.empty((b, tx, ty), dtype=torch.int32)
+        _check(lib().gtts_mas_maximum_path_cpu(_ptr(v), _ptr(m), _ptr(t_x), _ptr(t_y), _ptr(path), b, tx, ty),
+               "gtts_mas_maximum_path_cpu")
+        return path.to(dtype=value.dtype)
     v = value.detach().float().contiguous()
     m = mask.detach().to(device=v.device, dtype=torch.float32).contiguous()
     b, tx, ty = v.shape

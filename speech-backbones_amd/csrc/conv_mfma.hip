@@ -26,14 +26,22 @@
 // Wave tile: (MF x 32) output channels x (2 rows x 32 columns) pixels; a workgroup is WM x WN waves.
 #include "common.h"
 #include <algorithm>
+#include <atomic>
 
 // minimum waves per SIMD requested from the register allocator (= workgroups per CU with 4-wave workgroups)
 #ifndef GTTS_C3_WAVES
 #define GTTS_C3_WAVES 3
 #endif
 #define GTTS_WAVES(MODE) ((MODE) == CONV_DN ? 2 : GTTS_C3_WAVES)
-// GTTS_EXP: timing-only ablations of the main loop (results are WRONG; never set in a product build)
+// Diagnostics exist only in -DGTTS_DIAG builds (tools/abexp.sh, tools/trace_conv.py); the product library is compiled
+// without it and the three switches below are then forced off, whatever else is on the command line.
+// GTTS_EXP: timing-only ablations of the main loop (results are WRONG)
 //   1 no MFMAs   2 no fragment ds_reads   3 no activation transform/ds_write   4 no weight staging   5 no barriers
+#ifndef GTTS_DIAG
+#undef GTTS_EXP
+#undef GTTS_TRACE
+#undef GTTS_WDMA
+#endif
 #ifndef GTTS_EXP
 #define GTTS_EXP 0
 #endif
@@ -598,13 +606,17 @@ static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
     if (in_c * a.Hin * a.Win * 4 >= lim || (size_t)a.cout * a.Hout * a.Wout * 4 >= lim) return hipErrorInvalidValue;
     size_t smem = conv_smem_bytes(C::NPIX, C::NKG, C::WBLK16, a.cin, PRO, C::MT) +
                   (ConvWdma<MODE, WM, FULLC>::on ? (size_t)C::WBLK16 * 16 : 0);
-    static size_t attr_set = 0;
-    if (smem > attr_set) {
+    // hipFuncSetAttribute is per device: remember the largest size set on each device (atomics: launches may come
+    // from several host threads; setting the attribute twice is harmless)
+    static std::atomic<size_t> attr_set[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (smem > attr_set[dev].load(std::memory_order_relaxed)) {
         hipError_t e = hipFuncSetAttribute(
             reinterpret_cast<const void *>(&conv_mfma_kernel<MODE, WM, WN, MF, KCH, PRO, EPI, NSPLIT, FULLC>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
-        attr_set = smem;
+        attr_set[dev].store(smem, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, MF, KCH, PRO, EPI, NSPLIT, FULLC>), grid, dim3(256), smem, st, a);
     return hipGetLastError();

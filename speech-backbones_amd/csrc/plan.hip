@@ -10,7 +10,10 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
+
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -108,14 +111,21 @@ struct gtts_plan {
     struct ProfRec { int op; hipEvent_t a, b; };
     std::vector<ProfRec> prof;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
-    // sub-streams for the sampler's two-way batch split (created on first use)
+    // Caller-owned side streams for the sampler's sub-batch split (gtts_plan_set_streams); the fork / join events
+    // are host objects of the plan, created when the streams are registered.
+    int nsub = 0;
     hipStream_t sub[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
-    // workspace layout cache
+    // Execution state below (layout cache, profiling record) is mutated by the enqueueing calls: they take this
+    // mutex for the duration of the (host-side, asynchronous) enqueue, so one plan may be shared by several host
+    // threads / streams as long as each call brings its own workspace.
+    std::mutex mu;
+    // workspace layout cache of the enqueueing calls (guarded by mu)
     int cache_B = -1, cache_T = -1;
     std::vector<size_t> offsets;
     size_t ws_bytes = 0;
 };
+struct Layout { std::vector<size_t> offsets; size_t ws_bytes = 0; };
 
 // ------------------------------------------------------------------------------------------------ builders
 static int add_param(gtts_plan *p, const std::string &name, std::vector<int> dims, int pack, int cin = 0, int cout = 0) {
@@ -496,37 +506,47 @@ extern "C" int gtts_plan_create(const gtts_unet_cfg *cfg, gtts_plan **out) {
 
 extern "C" void gtts_plan_destroy(gtts_plan *plan) {
     if (!plan) return;
-    for (int h = 0; h < 4; ++h) {
-        if (plan->sub[h]) (void)hipStreamDestroy(plan->sub[h]);
-        if (plan->ev_join[h]) (void)hipEventDestroy(plan->ev_join[h]);
-    }
+    for (int h = 0; h < 4; ++h)
+        if (plan->ev_join[h]) (void)hipEventDestroy(plan->ev_join[h]);      // the side streams belong to the caller
     if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
     for (auto &e : plan->prof_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &r : plan->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     delete plan;
 }
 
-// GTTS_STREAMS=1..4: number of sub-batches the sampler runs side by side (1 disables the split).  Measured on MI355X at
-// B=16, T=1024: 8.23 / 7.88 / 7.76 / 9.02 ms per U-Net call for 1 / 2 / 3 / 4 -> default 3.
+// Sub-batch streams.  The sampler can run sub-batches of the utterance batch side by side on CALLER-OWNED side
+// streams registered with gtts_plan_set_streams (results are bit-identical to the unsplit run: no operation mixes
+// batch entries).  Measured on MI355X at B=16, T=1024: 8.23 / 7.88 / 7.76 / 9.02 ms per U-Net call for 1 / 2 / 3 / 4
+// sub-batches.  Without registered streams everything runs on the stream passed to the call.
 constexpr int MAX_SUB = 4;
-static int sampler_streams() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("GTTS_STREAMS");
-        v = (e && e[0] >= '1' && e[0] <= '0' + MAX_SUB && e[1] == 0) ? e[0] - '0' : 3;
+static int sampler_parts(const gtts_plan *p, int B) { return std::max(1, std::min(B, p->nsub)); }
+
+extern "C" int gtts_plan_set_streams(gtts_plan *plan, const gtts_stream_t *streams, int n) {
+    if (!plan) return fail(GTTS_E_NULL, "null plan");
+    if (n < 0 || n > MAX_SUB) return fail(GTTS_E_SHAPE, "at most %d side streams (got %d)", MAX_SUB, n);
+    if (n == 1) return fail(GTTS_E_SHAPE, "register 0 (no split) or 2..%d side streams", MAX_SUB);
+    if (n > 0 && !streams) return fail(GTTS_E_NULL, "gtts_plan_set_streams: null stream array");
+    std::lock_guard<std::mutex> lk(plan->mu);
+    for (int h = 0; h < n; ++h) {
+        if (!plan->ev_join[h]) HIPCHK(hipEventCreateWithFlags(&plan->ev_join[h], hipEventDisableTiming));
+        plan->sub[h] = (hipStream_t)streams[h];
     }
-    return v;
+    if (n > 0 && !plan->ev_fork) HIPCHK(hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming));
+    plan->nsub = n;
+    return GTTS_OK;
 }
-// GTTS_SKIP_OPS (diagnostics): bit 0 skip gn_finalize, bit 1 skip attn_merge + attn_fold (results WRONG);
-// bit 2 launch gn_finalize twice, bit 3 launch attn_merge / attn_fold twice (idempotent, results valid: the time
-// difference to the normal run is the in-situ cost of those launches)
-// Read on every call: a bench can run its warm-up normally and then skip the ops, so that the skipped ops' outputs
-// still hold realistic values (all-zero operands would raise the clock and flatter the result).
+
+#ifdef GTTS_DIAG
+// Diagnostic builds only (-DGTTS_DIAG, never the product library).  GTTS_SKIP_OPS: bit 0 skip gn_finalize, bit 1 skip
+// attn_merge + attn_fold (results WRONG); bit 2 launch gn_finalize twice, bit 3 launch attn_merge / attn_fold twice
+// (idempotent, results valid: the time difference to the normal run is the in-situ cost of those launches).
 static int skip_op_mask() {
     const char *e = getenv("GTTS_SKIP_OPS");
     return e ? atoi(e) : 0;
 }
-static int sampler_parts(int B) { return std::max(1, std::min(B, sampler_streams())); }
+#else
+static constexpr int skip_op_mask() { return 0; }
+#endif
 
 // registration order: spk_mlp, mlp, downs, ups, mid_block1, mid_attn, mid_block2, final_block, final_conv
 static int reg_rank(const std::string &n) {
@@ -609,17 +629,17 @@ static size_t tensor_bytes(const gtts_plan *p, const Tensor &t, int B, int T, in
 }
 
 // (B,T) -> offsets.  keep_intermediates: every tensor gets its own slot; otherwise first-fit reuse by liveness.
-static void layout_workspace(gtts_plan *p, int B, int T, int rows, int Tr = 0) {
+// Pure function of the plan (queries use it directly; the enqueueing calls cache its result under the plan mutex).
+static Layout compute_layout(const gtts_plan *p, int B, int T, int rows, int Tr) {
     if (Tr <= 0) Tr = T;
-    if (p->cache_B == B && p->cache_T == T * 4096 + rows && p->cache_Tr == Tr) return;
-    p->cache_Tr = Tr;
+    Layout L;
     const int n = (int)p->tensors.size();
-    p->offsets.assign(n, 0);
+    L.offsets.assign(n, 0);
     std::vector<size_t> sz(n);
     for (int i = 0; i < n; ++i) sz[i] = align_up(tensor_bytes(p, p->tensors[i], B, T, rows, Tr), 256);
     size_t top = 0;
     if (p->cfg.keep_intermediates) {
-        for (int i = 0; i < n; ++i) { p->offsets[i] = top; top += sz[i]; }
+        for (int i = 0; i < n; ++i) { L.offsets[i] = top; top += sz[i]; }
     } else {
         struct Blk { size_t off, size; int last; };
         std::vector<Blk> live;
@@ -637,12 +657,23 @@ static void layout_workspace(gtts_plan *p, int B, int T, int rows, int Tr = 0) {
                 if (pos + sz[id] <= b.off) break;
                 pos = std::max(pos, b.off + b.size);
             }
-            p->offsets[id] = pos;
+            L.offsets[id] = pos;
             live.push_back({pos, sz[id], t.last});
             top = std::max(top, pos + sz[id]);
         }
     }
-    p->ws_bytes = top;
+    L.ws_bytes = top;
+    return L;
+}
+
+// cached variant for the enqueueing calls (caller holds p->mu)
+static void layout_workspace(gtts_plan *p, int B, int T, int rows, int Tr = 0) {
+    if (Tr <= 0) Tr = T;
+    if (p->cache_B == B && p->cache_T == T * 4096 + rows && p->cache_Tr == Tr) return;
+    Layout L = compute_layout(p, B, T, rows, Tr);
+    p->offsets.swap(L.offsets);
+    p->ws_bytes = L.ws_bytes;
+    p->cache_Tr = Tr;
     p->cache_B = B;
     p->cache_T = T * 4096 + rows;
 }
@@ -656,15 +687,12 @@ static int check_shape(const gtts_plan *p, int B, int T) {
 
 extern "C" size_t gtts_workspace_bytes(const gtts_plan *plan, int B, int T) {
     if (check_shape(plan, B, T) != GTTS_OK) return 0;
-    gtts_plan *p = const_cast<gtts_plan *>(plan);
     // sized for the sampler's worst case: one tb row per step is tiny, allow up to 4096 rows
-    layout_workspace(p, B, T, std::max(B, 4096));
-    size_t whole = p->ws_bytes;
-    const int parts = sampler_parts(B);          // the sampler runs sub-batches side by side, each in its own slice
+    size_t whole = compute_layout(plan, B, T, std::max(B, 4096), T).ws_bytes;
+    const int parts = sampler_parts(plan, B);     // the sampler runs sub-batches side by side, each in its own slice
     if (parts > 1) {
         const int Bh = (B + parts - 1) / parts;
-        layout_workspace(p, Bh, T, std::max(Bh, 4096));
-        whole = std::max(whole, parts * align_up(p->ws_bytes, 256));
+        whole = std::max(whole, parts * align_up(compute_layout(plan, Bh, T, std::max(Bh, 4096), T).ws_bytes, 256));
     }
     return whole;
 }
@@ -682,11 +710,10 @@ extern "C" int gtts_vc_tensor_info(const gtts_plan *plan, int i, int B, int T, i
                                    int dims[4]) {
     if (check_shape(plan, B, T) != GTTS_OK) return GTTS_E_SHAPE;
     if (i < 0 || i >= (int)plan->tensors.size()) return fail(GTTS_E_SHAPE, "tensor index out of range");
-    gtts_plan *p = const_cast<gtts_plan *>(plan);
-    layout_workspace(p, B, T, std::max(B, 4096), T_ref);
+    const gtts_plan *p = plan;
     const Tensor &t = p->tensors[i];
     if (name) *name = t.name.c_str();
-    if (offset) *offset = p->offsets[i];
+    if (offset) *offset = compute_layout(p, B, T, std::max(B, 4096), T_ref).offsets[i];
     if (dims) {
         dims[0] = B; dims[1] = t.C; dims[2] = p->cfg.n_feats >> t.lvl; dims[3] = (t.tref ? T_ref : T) >> t.lvl;
         if (t.kind != TK_ACT) { dims[2] = 1; dims[3] = 1; }
@@ -697,7 +724,7 @@ extern "C" int gtts_vc_tensor_info(const gtts_plan *plan, int i, int B, int T, i
 
 // ------------------------------------------------------------------------------------------------ execution
 struct RunCtx {
-    const gtts_plan *p;
+    gtts_plan *p;
     const unsigned char *blob;
     unsigned char *ws;
     const float *mask;
@@ -717,7 +744,7 @@ struct ProfScope {
     gtts_plan *p;
     hipStream_t st;
     int idx;
-    ProfScope(const gtts_plan *plan, hipStream_t s, int op) : p(const_cast<gtts_plan *>(plan)), st(s), idx(-1) {
+    ProfScope(gtts_plan *plan, hipStream_t s, int op) : p(plan), st(s), idx(-1) {
         if (!p->prof_on) return;
         std::pair<hipEvent_t, hipEvent_t> ev;
         if (!p->prof_pool.empty()) { ev = p->prof_pool.back(); p->prof_pool.pop_back(); }
@@ -732,7 +759,7 @@ struct ProfScope {
 static inline float *tptr(const RunCtx &c, int id) { return id < 0 ? nullptr : (float *)(c.ws + c.p->offsets[id]); }
 
 static int run_ops(const RunCtx &c) {
-    const gtts_plan *p = c.p;
+    gtts_plan *p = c.p;
     const int F = p->cfg.n_feats, nsplit = p->cfg.precision == GTTS_PREC_BF16 ? 1 : 2;
     for (size_t oi = 0; oi < p->ops.size(); ++oi) {
         const Op &o = p->ops[oi];
@@ -850,10 +877,11 @@ static int run_ops(const RunCtx &c) {
     return GTTS_OK;
 }
 
-// t == nullptr: device computes t_i = float(1 - (i + 0.5)/n) per row (the sampler's schedule, diffusion.py:259)
-__global__ void sampler_times_kernel(float *t, int n) {
+// step times of the samplers, computed on the device in double like the reference's Python arithmetic:
+// Grad-TTS t_i = float(1 - (i + 0.5) h) (midpoint, diffusion.py:259), DiffVC t_i = float(1 - i h) (DiffVC/model/diffusion.py:170)
+__global__ void sampler_times_kernel(float *t, int n, double shift) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) t[i] = (float)(1.0 - ((double)i + 0.5) * (1.0 / (double)n));
+    if (i < n) t[i] = (float)(1.0 - ((double)i + shift) * (1.0 / (double)n));
 }
 
 static int prepare(gtts_plan *p, int B, int T, int rows, size_t workspace_bytes) {
@@ -863,14 +891,15 @@ static int prepare(gtts_plan *p, int B, int T, int rows, size_t workspace_bytes)
     return GTTS_OK;
 }
 
-extern "C" int gtts_estimator_forward(const gtts_plan *plan, const void *packed, const float *x, const float *mask,
+extern "C" int gtts_estimator_forward(gtts_plan *plan, const void *packed, const float *x, const float *mask,
                                       const float *mu, const float *t, const float *spk, float *out, void *workspace,
                                       size_t workspace_bytes, int B, int T, gtts_stream_t stream) {
     int rc = check_shape(plan, B, T);
     if (rc) return rc;
     if (!packed || !x || !mask || !mu || !t || !out || !workspace) return fail(GTTS_E_NULL, "gtts_estimator_forward: null argument");
     if (plan->cfg.arch != 0) return fail(GTTS_E_CONFIG, "gtts_estimator_forward needs a Grad-TTS plan (arch 0); use gtts_vc_estimator_forward");
-    gtts_plan *p = const_cast<gtts_plan *>(plan);
+    gtts_plan *p = plan;
+    std::lock_guard<std::mutex> lk(p->mu);
     const bool multi = p->cfg.n_spks > 1;
     if (multi && !spk) return fail(GTTS_E_NULL, "multi-speaker plan needs spk");
     rc = prepare(p, B, T, B, workspace_bytes);
@@ -906,15 +935,19 @@ extern "C" int gtts_euler_step(float *xt, const float *mu, const float *est, con
     return GTTS_OK;
 }
 
-extern "C" int gtts_reverse_diffusion(const gtts_plan *plan, const void *packed, const float *z, const float *mask,
+extern "C" int gtts_reverse_diffusion(gtts_plan *plan, const void *packed, const float *z, const float *mask,
                                       const float *mu, const float *spk, const float *noise, float *out, void *workspace,
-                                      size_t workspace_bytes, int B, int T, int n_timesteps, gtts_stream_t stream) {
+                                      size_t workspace_bytes, int B, int T, int n_timesteps, int step_begin, int step_end,
+                                      gtts_stream_t stream) {
     int rc = check_shape(plan, B, T);
     if (rc) return rc;
     if (!packed || !z || !mask || !mu || !out || !workspace) return fail(GTTS_E_NULL, "gtts_reverse_diffusion: null argument");
     if (n_timesteps <= 0 || n_timesteps > 4096) return fail(GTTS_E_SHAPE, "n_timesteps must be in [1, 4096], got %d", n_timesteps);
+    if (step_begin < 0 || step_end > n_timesteps || step_begin >= step_end)
+        return fail(GTTS_E_SHAPE, "step range [%d, %d) is not inside [0, %d)", step_begin, step_end, n_timesteps);
     if (plan->cfg.arch != 0) return fail(GTTS_E_CONFIG, "gtts_reverse_diffusion needs a Grad-TTS plan (arch 0); use gtts_vc_reverse_diffusion");
-    gtts_plan *p = const_cast<gtts_plan *>(plan);
+    gtts_plan *p = plan;
+    std::lock_guard<std::mutex> lk(p->mu);
     const bool multi = p->cfg.n_spks > 1;
     if (multi && !spk) return fail(GTTS_E_NULL, "multi-speaker plan needs spk");
     hipStream_t st = (hipStream_t)stream;
@@ -926,30 +959,22 @@ extern "C" int gtts_reverse_diffusion(const gtts_plan *plan, const void *packed,
     // overlap MFMA-bound ones.  Results are bit-identical to the unsplit run (no operation mixes batch entries).
     // per-op profiling (gtts_profile_enable) runs the batch unsplit: one launch per op owns the GPU, so an op's
     // HIP-event duration and its whole-batch algorithmic work describe the same thing
-    const int nhalf = p->prof_on ? 1 : sampler_parts(B);
+    const int nhalf = p->prof_on ? 1 : sampler_parts(p, B);
     const int Bh0 = (B + nhalf - 1) / nhalf;
     layout_workspace(p, Bh0, T, std::max(Bh0, 4096));
     const size_t ws_half = align_up(p->ws_bytes, 256);
     if (workspace_bytes < ws_half * nhalf)
         return fail(GTTS_E_WORKSPACE, "workspace too small: need %zu bytes, got %zu", ws_half * nhalf, workspace_bytes);
-    if (nhalf > 1 && !p->sub[nhalf - 1]) {
-        for (int h = 0; h < nhalf; ++h) {
-            if (p->sub[h]) continue;
-            HIPCHK(hipStreamCreateWithFlags(&p->sub[h], hipStreamNonBlocking));
-            HIPCHK(hipEventCreateWithFlags(&p->ev_join[h], hipEventDisableTiming));
-        }
-        if (!p->ev_fork) HIPCHK(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-    }
 
     RunCtx c0{p, blob, (unsigned char *)workspace, mask, B, T, nullptr, 0, st};
     // time embeddings of all N steps in one launch: t is batch-uniform inside the sampler (diffusion.py:259).
     // The step times live in the 4096 floats behind the tb rows.  Both halves read these rows.
     float *tb = tptr(c0, p->t_tb);
     float *tvals = tb + (size_t)std::max(Bh0, 4096) * p->tmlp.tb_stride;
-    hipLaunchKernelGGL(sampler_times_kernel, dim3((N + 255) / 256), dim3(256), 0, st, tvals, N);
+    hipLaunchKernelGGL(sampler_times_kernel, dim3((N + 255) / 256), dim3(256), 0, st, tvals, N, 0.5);
     HIPCHK(hipGetLastError());
     { ProfScope ps_(p, st, (int)p->ops.size() + XOP_TIME); HIPCHK(launch_time_mlp(tvals, (const float *)(blob + p->freq_off), p->cfg.pe_scale, blob, p->tmlp, tb, N, st)); }
-    { ProfScope ps_(p, st, (int)p->ops.size() + XOP_MULMASK); HIPCHK(launch_mul_mask(z, mask, out, B, F, T, st)); }           // xt = z * mask        (diffusion.py:257)
+    if (step_begin == 0) { ProfScope ps_(p, st, (int)p->ops.size() + XOP_MULMASK); HIPCHK(launch_mul_mask(z, mask, out, B, F, T, st)); }   // xt = z * mask  (diffusion.py:257)
 
     struct Half { RunCtx c; int b0; float *s; };
     Half hv[MAX_SUB];
@@ -965,44 +990,52 @@ extern "C" int gtts_reverse_diffusion(const gtts_plan *plan, const void *packed,
         HIPCHK(hipEventRecord(p->ev_fork, st));
         for (int h = 0; h < nhalf; ++h) HIPCHK(hipStreamWaitEvent(p->sub[h], p->ev_fork, 0));
     }
-    if (multi) {
-        for (int h = 0; h < nhalf; ++h) {
-            Half &H = hv[h];
-            if (H.c.B <= 0) continue;
-            H.s = tptr(H.c, p->t_s);
-            ProfScope ps_(p, H.c.st, (int)p->ops.size() + XOP_SPK);
-            HIPCHK(launch_spk_mlp(spk + (size_t)H.b0 * E, (const float *)(blob + p->spk_w0), (const float *)(blob + p->spk_b0),
-                                  (const float *)(blob + p->spk_w2), (const float *)(blob + p->spk_b2), H.s, H.c.B, E, F, H.c.st));
-        }
-    }
     const double hd = 1.0 / (double)N;
     const float h = (float)hd;
     const float bmin = p->cfg.beta_min, bdiff = (float)((double)p->cfg.beta_max - (double)p->cfg.beta_min);
-    for (int i = 0; i < N; ++i) {
-        const float t = (float)(1.0 - ((double)i + 0.5) * hd);
-        const float beta = bmin + bdiff * t;                      // get_noise, fp32 like the reference tensor math
-        for (int hh = 0; hh < nhalf; ++hh) {
-            Half &H = hv[hh];
-            if (H.c.B <= 0) continue;
-            const size_t off = (size_t)H.b0 * F * T;
-            H.c.tb_row = tb + (size_t)i * p->tmlp.tb_stride;
-            H.c.tb_bstride = 0;
-            { ProfScope ps_(p, H.c.st, (int)p->ops.size() + XOP_PREP); HIPCHK(launch_prep_input(mu + off, out + off, H.s, tptr(H.c, p->t_x0), H.c.B, F, T, p->cin0, H.c.st)); }
-            rc = run_ops(H.c);
-            if (rc) return rc;
-            const float *nz = noise ? noise + (size_t)i * B * F * T + off : nullptr;
-            { ProfScope ps_(p, H.c.st, (int)p->ops.size() + XOP_FINAL); HIPCHK(launch_final_euler(tptr(H.c, p->t_final_raw), tptr(H.c, p->t_final_sc), tptr(H.c, p->t_final_sh),
-                                      (const float *)(blob + p->fw_off), (const float *)(blob + p->fb_off), H.c.mask, H.c.B, p->cfg.dim, F, T,
-                                      nullptr, out + off, mu + off, nz, beta, h, H.c.st)); }
+    auto steps = [&]() -> int {
+        if (multi) {
+            for (int hh = 0; hh < nhalf; ++hh) {
+                Half &H = hv[hh];
+                if (H.c.B <= 0) continue;
+                H.s = tptr(H.c, p->t_s);
+                ProfScope ps_(p, H.c.st, (int)p->ops.size() + XOP_SPK);
+                HIPCHK(launch_spk_mlp(spk + (size_t)H.b0 * E, (const float *)(blob + p->spk_w0), (const float *)(blob + p->spk_b0),
+                                      (const float *)(blob + p->spk_w2), (const float *)(blob + p->spk_b2), H.s, H.c.B, E, F, H.c.st));
+            }
         }
-    }
+        for (int i = step_begin; i < step_end; ++i) {
+            const float t = (float)(1.0 - ((double)i + 0.5) * hd);
+            const float beta = bmin + bdiff * t;                      // get_noise, fp32 like the reference tensor math
+            for (int hh = 0; hh < nhalf; ++hh) {
+                Half &H = hv[hh];
+                if (H.c.B <= 0) continue;
+                const size_t off = (size_t)H.b0 * F * T;
+                H.c.tb_row = tb + (size_t)i * p->tmlp.tb_stride;
+                H.c.tb_bstride = 0;
+                { ProfScope ps_(p, H.c.st, (int)p->ops.size() + XOP_PREP); HIPCHK(launch_prep_input(mu + off, out + off, H.s, tptr(H.c, p->t_x0), H.c.B, F, T, p->cin0, H.c.st)); }
+                const int rc2 = run_ops(H.c);
+                if (rc2) return rc2;
+                const float *nz = noise ? noise + (size_t)(i - step_begin) * B * F * T + off : nullptr;
+                { ProfScope ps_(p, H.c.st, (int)p->ops.size() + XOP_FINAL); HIPCHK(launch_final_euler(tptr(H.c, p->t_final_raw), tptr(H.c, p->t_final_sc), tptr(H.c, p->t_final_sh),
+                                          (const float *)(blob + p->fw_off), (const float *)(blob + p->fb_off), H.c.mask, H.c.B, p->cfg.dim, F, T,
+                                          nullptr, out + off, mu + off, nz, beta, h, H.c.st)); }
+            }
+        }
+        return GTTS_OK;
+    };
+    rc = steps();
+    // join the side streams on EVERY exit path after the fork: the caller may free z / mu / out / workspace as soon as
+    // its stream has drained, so work already enqueued on the side streams must be ordered before that point
     if (nhalf > 1) {
         for (int hh = 0; hh < nhalf; ++hh) {
-            HIPCHK(hipEventRecord(p->ev_join[hh], p->sub[hh]));
-            HIPCHK(hipStreamWaitEvent(st, p->ev_join[hh], 0));
+            if (hipEventRecord(p->ev_join[hh], p->sub[hh]) != hipSuccess || hipStreamWaitEvent(st, p->ev_join[hh], 0) != hipSuccess) {
+                (void)hipStreamSynchronize(p->sub[hh]);       // last resort: never leave un-joined work behind
+                if (rc == GTTS_OK) rc = fail(GTTS_E_HIP, "joining sub-batch stream %d failed", hh);
+            }
         }
     }
-    return GTTS_OK;
+    return rc;
 }
 
 
@@ -1017,19 +1050,18 @@ static int vc_check(const gtts_plan *plan, int B, int T, int Tr) {
 
 extern "C" size_t gtts_vc_workspace_bytes(const gtts_plan *plan, int B, int T, int T_ref) {
     if (vc_check(plan, B, T, T_ref) != GTTS_OK) return 0;
-    gtts_plan *p = const_cast<gtts_plan *>(plan);
-    layout_workspace(p, B, T, std::max(B, 4096), T_ref);
-    return p->ws_bytes;
+    return compute_layout(plan, B, T, std::max(B, 4096), T_ref).ws_bytes;
 }
 
-extern "C" int gtts_vc_estimator_forward(const gtts_plan *plan, const void *packed, const float *x, const float *x_mask,
+extern "C" int gtts_vc_estimator_forward(gtts_plan *plan, const void *packed, const float *x, const float *x_mask,
                                          const float *mean, const float *xt_ref, const float *ref_mask, const float *c,
                                          const float *t, float *out, void *workspace, size_t workspace_bytes, int B, int T,
                                          int T_ref, gtts_stream_t stream) {
     int rc = vc_check(plan, B, T, T_ref);
     if (rc) return rc;
     if (!packed || !x || !x_mask || !mean || !c || !t || !out || !workspace) return fail(GTTS_E_NULL, "gtts_vc_estimator_forward: null argument");
-    gtts_plan *p = const_cast<gtts_plan *>(plan);
+    gtts_plan *p = plan;
+    std::lock_guard<std::mutex> lk(p->mu);
     if (p->cfg.use_ref_t && (!xt_ref || !ref_mask)) return fail(GTTS_E_NULL, "use_ref_t plan needs xt_ref and ref_mask");
     layout_workspace(p, B, T, std::max(B, 4096), T_ref);
     if (workspace_bytes < p->ws_bytes) return fail(GTTS_E_WORKSPACE, "workspace too small: need %zu bytes, got %zu", p->ws_bytes, workspace_bytes);
@@ -1059,18 +1091,21 @@ static double vc_gamma(const gtts_unet_cfg &cf, double s, double t, double pw = 
     return exp(-0.5 * pw * bi);
 }
 
-extern "C" int gtts_vc_reverse_diffusion(const gtts_plan *plan, const void *packed, const float *z, const float *mask,
+extern "C" int gtts_vc_reverse_diffusion(gtts_plan *plan, const void *packed, const float *z, const float *mask,
                                          const float *mean, const float *ref, const float *ref_mask, const float *mean_ref,
                                          const float *c, const float *noise, float *out, void *workspace,
                                          size_t workspace_bytes, int B, int T, int T_ref, int n_timesteps, int mode,
-                                         gtts_stream_t stream) {
+                                         int step_begin, int step_end, gtts_stream_t stream) {
     int rc = vc_check(plan, B, T, T_ref);
     if (rc) return rc;
+    if (n_timesteps > 0 && (step_begin < 0 || step_end > n_timesteps || step_begin >= step_end))
+        return fail(GTTS_E_SHAPE, "step range [%d, %d) is not inside [0, %d)", step_begin, step_end, n_timesteps);
     if (!packed || !z || !mask || !mean || !c || !out || !workspace) return fail(GTTS_E_NULL, "gtts_vc_reverse_diffusion: null argument");
     if (n_timesteps <= 0 || n_timesteps > 4096) return fail(GTTS_E_SHAPE, "n_timesteps must be in [1, 4096], got %d", n_timesteps);
     if (mode < 0 || mode > 2) return fail(GTTS_E_CONFIG, "mode must be 0 ('pf'), 1 ('em') or 2 ('ml')");
     if (mode != 0 && !noise) return fail(GTTS_E_NULL, "'em' / 'ml' sampling needs the pre-drawn noise tensor");
-    gtts_plan *p = const_cast<gtts_plan *>(plan);
+    gtts_plan *p = plan;
+    std::lock_guard<std::mutex> lk(p->mu);
     const gtts_unet_cfg &cf = p->cfg;
     if (cf.use_ref_t && (!ref || !ref_mask || !mean_ref)) return fail(GTTS_E_NULL, "use_ref_t plan needs ref, ref_mask and mean_ref");
     layout_workspace(p, B, T, std::max(B, 4096), T_ref);
@@ -1083,14 +1118,12 @@ extern "C" int gtts_vc_reverse_diffusion(const gtts_plan *plan, const void *pack
     // step times t_i = 1 - i*h (left endpoint, diffusion.py:170) -> fp32 `time` tensor values, all rows in one launch
     float *tb = tptr(cx, p->t_tb);
     float *tvals = tb + (size_t)std::max(B, 4096) * p->tmlp.tb_stride;
-    std::vector<float> th(N);
     const double hd = 1.0 / (double)N;
-    for (int i = 0; i < N; ++i) th[i] = (float)(1.0 - (double)i * hd);
-    HIPCHK(hipMemcpyAsync(tvals, th.data(), (size_t)N * sizeof(float), hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));      // th is a host temporary
+    hipLaunchKernelGGL(sampler_times_kernel, dim3((N + 255) / 256), dim3(256), 0, st, tvals, N, 0.0);
+    HIPCHK(hipGetLastError());
     { ProfScope ps_(p, st, (int)p->ops.size() + XOP_TIME); HIPCHK(launch_time_mlp(tvals, (const float *)(blob + p->freq_off), cf.pe_scale, blob, p->tmlp, tb, N, st)); }
-    { ProfScope ps_(p, st, (int)p->ops.size() + XOP_MULMASK); HIPCHK(launch_mul_mask(z, mask, out, B, F, T, st)); }
-    for (int i = 0; i < N; ++i) {
+    if (step_begin == 0) { ProfScope ps_(p, st, (int)p->ops.size() + XOP_MULMASK); HIPCHK(launch_mul_mask(z, mask, out, B, F, T, st)); }
+    for (int i = step_begin; i < step_end; ++i) {
         const double t = 1.0 - (double)i * hd;
         const double beta_t = cf.vc_beta_min + (cf.vc_beta_max - cf.vc_beta_min) * t;
         double kappa = 0.0, omega = 0.0, sigma = 0.0;
@@ -1122,7 +1155,7 @@ extern "C" int gtts_vc_reverse_diffusion(const gtts_plan *plan, const void *pack
         cx.tb_bstride = 0;
         rc = run_ops(cx);
         if (rc) return rc;
-        const float *nz = (mode != 0) ? noise + (size_t)i * B * F * T : nullptr;
+        const float *nz = (mode != 0) ? noise + (size_t)(i - step_begin) * B * F * T : nullptr;
         { ProfScope ps_(p, st, (int)p->ops.size() + XOP_FINAL); HIPCHK(launch_final_euler(tptr(cx, p->t_final_raw), tptr(cx, p->t_final_sc), tptr(cx, p->t_final_sh),
                                   (const float *)(blob + p->fw_off), (const float *)(blob + p->fb_off), mask, B, cf.dim, F, T,
                                   nullptr, out, mean, nz, 0.f, 0.f, st, &vs)); }
@@ -1144,6 +1177,63 @@ extern "C" int gtts_mas_maximum_path(const float *value, const float *mask, cons
     return GTTS_OK;
 }
 
+
+// CPU twin: the reference's maximum_path accepts tensors on any device and always runs its Cython kernel on the host
+// (monotonic_align/__init__.py:8-23).  Same arithmetic as the GPU kernel and core.pyx:9-45: one fp32 max and one fp32
+// add per cell, strict '<' in the backtrack -> bit-identical paths.  value / mask / path are HOST pointers.
+extern "C" int gtts_mas_maximum_path_cpu(const float *value, const float *mask, const int *t_x, const int *t_y, int *path,
+                                         int b, int tx, int ty) {
+    if (!value || !t_x || !t_y || !path) return fail(GTTS_E_NULL, "gtts_mas_maximum_path_cpu: null argument");
+    if (b <= 0 || tx <= 0 || ty <= 0) return fail(GTTS_E_SHAPE, "gtts_mas_maximum_path_cpu: bad shape b=%d tx=%d ty=%d", b, tx, ty);
+    const float NEG = -1e9f;
+    std::vector<float> v((size_t)tx * ty);
+    for (int i = 0; i < b; ++i) {
+        const size_t base = (size_t)i * tx * ty;
+        int *pp = path + base;
+        memset(pp, 0, (size_t)tx * ty * sizeof(int));
+        const int X = t_x[i], Y = t_y[i];
+        if (X <= 0 || Y <= 0 || X > tx || Y > ty) continue;
+        for (size_t k = 0; k < (size_t)tx * ty; ++k) v[k] = mask ? value[base + k] * mask[base + k] : value[base + k];
+        for (int y = 0; y < Y; ++y) {
+            const int lo = std::max(0, X + y - Y), hi = std::min(X, y + 1);
+            for (int x = lo; x < hi; ++x) {
+                const float v_cur = (x == y) ? NEG : v[(size_t)x * ty + y - 1];
+                float v_prev;
+                if (x == 0) v_prev = (y == 0) ? 0.f : NEG;
+                else v_prev = v[(size_t)(x - 1) * ty + y - 1];
+                v[(size_t)x * ty + y] = (v_cur > v_prev ? v_cur : v_prev) + v[(size_t)x * ty + y];
+            }
+        }
+        int index = X - 1;
+        for (int y = Y - 1; y >= 0; --y) {
+            pp[(size_t)index * ty + y] = 1;
+            if (index != 0 && (index == y || (y > 0 && v[(size_t)index * ty + y - 1] < v[(size_t)(index - 1) * ty + y - 1]))) index -= 1;
+        }
+    }
+    return GTTS_OK;
+}
+
+// The one collective of the multi-GPU path: broadcast of the packed weight blob from `root` over RCCL.
+// `comm` is the caller's ncclComm_t.  RCCL is resolved at call time from the process (the copy PyTorch-ROCm already
+// loaded) or, failing that, from librccl.so -- the library itself carries no link-time dependency on it.
+extern "C" int gtts_bcast_weights(void *packed, size_t bytes, int root, void *comm, gtts_stream_t stream) {
+    if (!packed || !comm) return fail(GTTS_E_NULL, "gtts_bcast_weights: null argument");
+    typedef int (*bcast_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+    static bcast_fn fn = nullptr;
+    if (!fn) {
+        void *sym = dlsym(RTLD_DEFAULT, "ncclBroadcast");
+        if (!sym) {
+            void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (h) sym = dlsym(h, "ncclBroadcast");
+        }
+        if (!sym) return fail(GTTS_E_HIP, "gtts_bcast_weights: RCCL (ncclBroadcast) is not available in this process");
+        fn = (bcast_fn)sym;
+    }
+    const int rc = fn(packed, packed, bytes, /*ncclChar*/ 0, root, comm, (hipStream_t)stream);
+    if (rc != 0) return fail(GTTS_E_HIP, "ncclBroadcast failed with code %d", rc);
+    return GTTS_OK;
+}
 
 extern "C" int gtts_expand_alignment(const float *duration, const float *x_mask, const int *y_lengths, const float *mu_x,
                                      const float *noise, float temperature, float *attn, float *mu_y, float *z, int B, int F,

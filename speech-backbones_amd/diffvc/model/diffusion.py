@@ -58,17 +58,25 @@ class GradLogPEstimator(BaseModule):
     def _plan(self):
         if tuple(self.dim_mults) != (1, 2, 4):
             raise RuntimeError("the HIP path supports dim_mults=(1,2,4) (the reference's configuration)")
-        if self._hip_plan is None:
+        key = (float(self._beta_range[0]), float(self._beta_range[1]))
+        if self._hip_plan is None or getattr(self, "_hip_plan_key", None) != key:
             self._hip_plan = backend().Plan(dim=self.dim_base, arch=1, dim_cond=self.dim_cond, use_ref_t=self.use_ref_t,
-                                            c_dim=256, pe_scale=1000.0, beta_min=float(self._beta_range[0]),
-                                            beta_max=float(self._beta_range[1]))
+                                            c_dim=256, pe_scale=1000.0, beta_min=key[0], beta_max=key[1])
+            self._hip_plan_key = key
+            self.invalidate_packed()
         return self._hip_plan
 
+    def invalidate_packed(self):
+        """Drop the packed blob (needed after edits through `p.data`, which do not bump Tensor._version)."""
+        self._hip_blob = None
+        self._hip_key = None
+
     def _packed(self, device):
+        plan = self._plan()
         params = list(self.named_parameters())
         key = (str(device),) + tuple((p.data_ptr(), p._version) for _, p in params)
         if self._hip_blob is None or self._hip_key != key:
-            self._hip_blob = self._plan().pack({n: p for n, p in params}, device)
+            self._hip_blob = plan.pack({n: p for n, p in params}, device)
             self._hip_key = key
         return self._hip_blob
 
@@ -160,7 +168,9 @@ class Diffusion(BaseModule):
         est._beta_range = (float(self.beta_min), float(self.beta_max))
         noise = None
         if mode != "pf":
-            noise = torch.stack([torch.randn_like(z, device=z.device) for _ in range(n_timesteps)])
+            # the reference's draws, in its order (one randn_like(z) per step), handed over in bounded chunks
+            def noise(k):
+                return torch.stack([torch.randn_like(z, device=z.device) for _ in range(k)])
         return est._plan().vc_reverse_diffusion(est._packed(z.device), z, mask, mean, ref, ref_mask, mean_ref, c,
                                                 n_timesteps, mode, noise)
 

@@ -53,7 +53,12 @@ def shard_by_frames(lengths, world):
 def broadcast_packed(blob, src=0):
     """Rank `src` packed the weights; everyone else receives the blob (uint8 tensor, same size everywhere)."""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.broadcast(blob, src=src)
+        if blob.is_cuda and dist.get_backend() == "gloo":      # CPU test rigs: stage through the host
+            host = blob.cpu()
+            dist.broadcast(host, src=src)
+            blob.copy_(host)
+        else:
+            dist.broadcast(blob, src=src)                      # RCCL (ncclBroadcast) over xGMI
     return blob
 
 

@@ -181,8 +181,12 @@ class GradLogPEstimator2d(BaseModule):
         self._beta_range = (0.05, 20.0)
         self._precision = None          # None -> backend default (bf16x3)
         self._hip_plan = None
+        self._hip_plan_key = None
         self._hip_blob = None
         self._hip_key = None
+        # load_state_dict() replaces parameter contents in place (copy_ bumps _version, so the key below would catch
+        # it anyway); the hook makes the repack explicit and independent of that detail
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed())
 
     # ---- HIP plumbing -------------------------------------------------------------------------------
     def set_precision(self, precision):
@@ -190,26 +194,41 @@ class GradLogPEstimator2d(BaseModule):
         be = backend()
         self._precision = {"bf16x3": be.PREC_BF16X3, "bf16": be.PREC_BF16}[precision]
         self._hip_plan = None
+        self.invalidate_packed()
+
+    def invalidate_packed(self):
+        """Drop the packed-weight blob; the next sampling call re-packs from the current parameters.
+
+        The automatic check below keys on (data_ptr, Tensor._version) of every parameter, which sees optimizer steps,
+        load_state_dict, .to() and ordinary in-place ops -- but NOT writes made through `p.data` (`p.data.copy_()`,
+        `p.data.mul_()`, as EMA weight swaps do): those do not bump `_version`.  Call this after such an edit."""
+        self._hip_blob = None
         self._hip_key = None
 
     def _plan(self):
         if tuple(self.dim_mults) != (1, 2, 4) or self.groups != 8:
             raise RuntimeError("the HIP path supports dim_mults=(1,2,4), groups=8 (the reference's configuration)")
-        if self._hip_plan is None:
-            be = backend()
-            prec = be.PREC_BF16X3 if self._precision is None else self._precision
+        be = backend()
+        prec = be.PREC_BF16X3 if self._precision is None else self._precision
+        # everything the plan captures at creation is part of the key: changing beta_min / beta_max / pe_scale on the
+        # module after the first sample rebuilds the plan (the ODE sampler takes beta from the plan's cfg)
+        key = (prec, float(self._beta_range[0]), float(self._beta_range[1]), float(self.pe_scale))
+        if self._hip_plan is None or self._hip_plan_key != key:
             self._hip_plan = be.Plan(dim=self.dim, n_feats=self.n_feats, n_spks=self.n_spks,
                                      spk_emb_dim=self.spk_emb_dim, groups=self.groups, pe_scale=float(self.pe_scale),
-                                     beta_min=float(self._beta_range[0]), beta_max=float(self._beta_range[1]),
-                                     precision=prec)
+                                     beta_min=key[1], beta_max=key[2], precision=prec)
+            self._hip_plan_key = key
+            self.invalidate_packed()
         return self._hip_plan
 
     def _packed(self, device):
-        """Packed weights, re-packed whenever a parameter changed (optimizer step, load_state_dict, .to())."""
+        """Packed weights, re-packed whenever a parameter changed (optimizer step, load_state_dict, .to()); see
+        invalidate_packed() for the one case the check cannot see."""
+        plan = self._plan()
         params = list(self.named_parameters())
         key = (str(device),) + tuple((p.data_ptr(), p._version) for _, p in params)
         if self._hip_blob is None or self._hip_key != key:
-            self._hip_blob = self._plan().pack({n: p for n, p in params}, device)
+            self._hip_blob = plan.pack({n: p for n, p in params}, device)
             self._hip_key = key
         return self._hip_blob
 

@@ -4,6 +4,7 @@ import importlib
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -60,6 +61,58 @@ def test_two_rank_shard_and_broadcast():
     assert all(r[0] and r[1] for r in res)
     assert all(abs(r[2] - 2.0) < 1e-9 for r in res)           # max over ranks
     assert sorted(r[3] for r in res) == [(0, 3), (3, 5)]
+
+
+def _gpu_worker(rank, world, port, q):
+    """The real N>1 path of bench.py on one visible GPU: rank 0 packs, the blob is broadcast, every rank samples its
+    contiguous utterance shard with the HIP kernels; rank 0 checks concatenation == unsharded run, bit for bit."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from oracle import gradtts_oracle as O
+    S = importlib.import_module("speech-backbones_amd")
+    D = importlib.import_module("speech-backbones_amd.dist")
+    D.init_from_env(backend="gloo")
+    dev = torch.device("cuda:0")
+    plan = S.Plan()
+    if rank == 0:
+        blob = plan.pack(O.make_estimator_state(seed=0), dev)
+    else:
+        blob = torch.zeros(plan.packed_bytes(), dtype=torch.uint8, device=dev)
+    D.broadcast_packed(blob, src=0)
+    inp = O.make_inputs(5, 64, seed=3)
+    lo, hi = D.shard_bounds(5, world, rank)
+    z, m, mu = (inp[k][lo:hi].contiguous().to(dev) for k in ("z", "mask", "mu"))
+    local = plan.reverse_diffusion(blob, z, m, mu, 4).cpu()
+    outs = D.gather_outputs(local, dst=0)
+    t = D.max_over_ranks(1.0 + rank, torch.device("cpu"))
+    ok = True
+    if rank == 0:
+        whole = plan.reverse_diffusion(blob, inp["z"].to(dev), inp["mask"].to(dev), inp["mu"].to(dev), 4).cpu()
+        ref = O.reverse_diffusion(O.make_estimator_state(seed=0), inp["z"], inp["mask"], inp["mu"], 4)
+        ok = bool(torch.equal(torch.cat(outs, 0), whole)) and float((whole - ref).abs().max() / ref.abs().max()) < 1e-4
+    D.barrier()
+    q.put((ok, t, (lo, hi)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_run_the_real_sampler_on_their_shards():
+    assert torch.cuda.is_available()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(r[0] for r in res)
+    assert all(abs(r[1] - 2.0) < 1e-9 for r in res)
+    assert sorted(r[2] for r in res) == [(0, 3), (3, 5)]
 
 
 def test_shard_helpers():
