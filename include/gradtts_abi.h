@@ -49,7 +49,10 @@ enum {
 /* precision of the dense contractions (3x3 / 1x1 / transposed convs, attention products) */
 enum {
     GTTS_PREC_BF16X3 = 0,    /* split-bf16 (hi/lo, 3 MFMAs, fp32 accumulate): fp32-grade accuracy (default) */
-    GTTS_PREC_BF16 = 1       /* single bf16 MFMA, fp32 accumulate (BASELINE.json config 3)                  */
+    GTTS_PREC_BF16 = 1,      /* single bf16 MFMA, fp32 accumulate, fp32 activation storage                   */
+    GTTS_PREC_BF16_STORE = 2 /* BASELINE.json config 3 as written: single bf16 MFMA, fp32 accumulate, and every
+                                activation tensor of the U-Net stored as bf16 (weights are bf16 already); GroupNorm
+                                statistics come from the fp32 accumulators before rounding.  Grad-TTS plans only. */
 };
 
 typedef void *gtts_stream_t; /* hipStream_t */
@@ -99,6 +102,13 @@ size_t gtts_workspace_bytes(const gtts_plan *plan, int B, int T);
  * of the utterance batch side by side (bit-identical results; utterances are independent).  n = 0 (default): everything
  * runs on the stream passed to the call.  The streams must outlive the plan or be unregistered (n = 0) first. */
 int gtts_plan_set_streams(gtts_plan *plan, const gtts_stream_t *streams, int n);
+
+/* on != 0: gtts_reverse_diffusion captures the launches of a call into a hipGraph the first time it sees an argument
+ * tuple (all pointers, shapes and the step range are part of the key) and replays it with one hipGraphLaunch on later
+ * calls with the same tuple -- for the launch-bound small-batch regime (B = 1 inference, Grad-TTS/inference.py:62-76).
+ * Keep the buffers alive and at the same addresses to hit the cache (at most 8 graphs are kept, LRU).  on == 0 drops
+ * the cached graphs.  Results are identical to the eager path (same kernels, same order). */
+int gtts_plan_set_graph(gtts_plan *plan, int on);
 
 /* Re-layout the estimator parameters (device fp32 pointers, in gtts_plan_param_info order) into the packed
  * blob the kernels read (bf16 hi/lo MFMA fragment order for conv weights, fp32 for the rest).
@@ -168,6 +178,11 @@ int gtts_bcast_weights(void *packed, size_t bytes, int root, void *comm, gtts_st
 int gtts_expand_alignment(const float *duration, const float *x_mask, const int *y_lengths, const float *mu_x,
                           const float *noise, float temperature, float *attn, float *mu_y, float *z, int B, int F,
                           int t_x, int T, gtts_stream_t stream);
+
+/* ---- MAS score matrix of GradTTS.compute_loss  (tts.py:130-139): log N(y_j; mu_x_i, I) for every (token i, frame j) --
+ * mu_x [B,F,t_x], y [B,F,T] -> log_prior [B,t_x,T] (fp32, feeds gtts_mas_maximum_path without leaving the device).
+ * Evaluated as -0.5 sum_f (y - mu)^2 - 0.5 F log(2 pi): equal to the reference's three-matmul form up to fp32 rounding. */
+int gtts_log_prior(const float *mu_x, const float *y, float *log_prior, int B, int F, int t_x, int T, gtts_stream_t stream);
 
 /* ---- debugging / tests: named intermediates of the last estimator call (keep_intermediates plans) ----- */
 int gtts_plan_num_tensors(const gtts_plan *plan);

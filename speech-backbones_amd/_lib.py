@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("GTTS_LIB", os.path.join(_HERE, "libgradtts_gfx950.so"
 
 PREC_BF16X3 = 0
 PREC_BF16 = 1
+PREC_BF16_STORE = 2
 
 _lib = None
 _lock = threading.Lock()
@@ -54,6 +55,7 @@ def lib():
         L.gtts_workspace_bytes.argtypes = [vp, i, i]
         L.gtts_workspace_bytes.restype = sz
         L.gtts_plan_set_streams.argtypes = [vp, ctypes.POINTER(vp), i]
+        L.gtts_plan_set_graph.argtypes = [vp, i]
         L.gtts_mas_maximum_path_cpu.argtypes = [vp, vp, vp, vp, vp, i, i, i]
         L.gtts_bcast_weights.argtypes = [vp, sz, i, vp, vp]
         L.gtts_pack_weights.argtypes = [vp, ctypes.POINTER(vp), i, vp, vp, vp]
@@ -64,6 +66,7 @@ def lib():
         L.gtts_mas_scratch_bytes.restype = sz
         L.gtts_mas_maximum_path.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, vp]
         L.gtts_expand_alignment.argtypes = [vp, vp, vp, vp, vp, f, vp, vp, vp, i, i, i, i, vp]
+        L.gtts_log_prior.argtypes = [vp, vp, vp, i, i, i, i, vp]
         L.gtts_plan_num_tensors.argtypes = [vp]
         L.gtts_plan_tensor_info.argtypes = [vp, i, i, i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz),
                                             ctypes.POINTER(i * 4)]
@@ -132,6 +135,8 @@ class Plan:
             streams = int(os.environ.get("GTTS_STREAMS", "3"))
         self._nstreams = 0 if int(streams) < 2 else min(int(streams), 4)
         self._side = None           # (device, [torch.cuda.Stream])
+        self._graph = False
+        self._stage = {}            # graph mode: persistent argument buffers (stable addresses -> graph cache hits)
 
     # a Plan is host metadata: copies / pickles rebuild it from its constructor arguments (EMA deep copies,
     # torch.save(model) of a module that already sampled)
@@ -140,6 +145,13 @@ class Plan:
 
     def __deepcopy__(self, memo):
         return Plan(**self._kw)
+
+    def set_graph(self, on=True):
+        """hipGraph replay of whole reverse_diffusion calls (launch-bound small batches).  Inputs are copied into
+        persistent buffers owned by this object so that every call presents the same addresses to the library."""
+        _check(lib().gtts_plan_set_graph(self._h, 1 if on else 0), "gtts_plan_set_graph")
+        self._graph = bool(on)
+        self._stage = {}
 
     def _use_streams(self, device):
         """Register this plan's side streams for `device` (created once; they belong to this object)."""
@@ -243,14 +255,28 @@ class Plan:
             raise RuntimeError("shape mismatch: z %s mask %s mu %s" % (tuple(z.shape), tuple(mask.shape), tuple(mu.shape)))
         if noise is not None and tuple(noise.shape) != (int(n_timesteps), B, F, T):
             raise RuntimeError("noise must be [n_timesteps, B, F, T]")
-        out = torch.empty_like(z)
         self._use_streams(z.device)
         ws = self.workspace(B, T, z.device)
+        if self._graph:
+            key = (B, T, str(z.device), spk is not None, None if noise is None else tuple(noise.shape))
+            st = self._stage.get(key)
+            if st is None:
+                self._stage.clear()
+                st = {"z": torch.empty_like(z), "mask": torch.empty_like(mask), "mu": torch.empty_like(mu),
+                      "out": torch.empty_like(z), "spk": None if spk is None else torch.empty_like(spk),
+                      "noise": None if noise is None else torch.empty_like(noise)}
+                self._stage[key] = st
+            for k, v in (("z", z), ("mask", mask), ("mu", mu), ("spk", spk), ("noise", noise)):
+                if v is not None:
+                    st[k].copy_(v)
+            z, mask, mu, spk, noise, out = st["z"], st["mask"], st["mu"], st["spk"], st["noise"], st["out"]
+        else:
+            out = torch.empty_like(z)
         with torch.cuda.device(z.device):
             _check(lib().gtts_reverse_diffusion(self._h, _ptr(blob), _ptr(z), _ptr(mask), _ptr(mu), _ptr(spk),
                                                 _ptr(noise), _ptr(out), _ptr(ws), ws.numel(), B, T, int(n_timesteps),
                                                 0, int(n_timesteps), _stream()), "gtts_reverse_diffusion")
-        return out
+        return out.clone() if self._graph else out
 
     # ---- DiffVC (arch=1)
     def vc_workspace(self, B, T, Tr, device):
@@ -413,6 +439,21 @@ def mas_maximum_path(value, mask):
         _check(lib().gtts_mas_maximum_path(_ptr(v), _ptr(m), _ptr(t_x), _ptr(t_y), _ptr(path), _ptr(scratch), b, tx,
                                            ty, _stream()), "gtts_mas_maximum_path")
     return path.to(dtype=value.dtype)
+
+
+def log_prior(mu_x, y):
+    """MAS score matrix of GradTTS.compute_loss (tts.py:130-139): [B,F,t_x], [B,F,T] -> [B,t_x,T], one launch."""
+    if not mu_x.is_cuda:
+        raise RuntimeError("log_prior needs HIP tensors; there is no CPU fallback")
+    mx, yy = _f32c(mu_x.detach(), "mu_x"), _f32c(y.detach(), "y")
+    B, F, tx = mx.shape
+    if yy.shape[0] != B or yy.shape[1] != F:
+        raise RuntimeError("mu_x [B,F,t_x] and y [B,F,T] disagree: %s vs %s" % (tuple(mx.shape), tuple(yy.shape)))
+    T = yy.shape[2]
+    out = torch.empty((B, tx, T), dtype=torch.float32, device=mx.device)
+    with torch.cuda.device(mx.device):
+        _check(lib().gtts_log_prior(_ptr(mx), _ptr(yy), _ptr(out), B, F, tx, T, _stream()), "gtts_log_prior")
+    return out
 
 
 def expand_alignment(duration, x_mask, y_lengths, mu_x, T, noise=None, temperature=1.0):

@@ -20,7 +20,7 @@
 namespace gtts {
 
 struct AttnCtxArgs {
-    const float *x;
+    const void *x;
     const unsigned char *wkv;
     float *partials;
     int C, HW, nstage, tiles, tps, nrec, nsplit, B;
@@ -40,8 +40,9 @@ __device__ __forceinline__ void pack8_split(const float (&v)[8], u32x4 &hi, u32x
 }
 
 // FULLC: C is a multiple of 32 (every staged channel exists)
-template <int NSPLIT, int FULLC>
+template <int NSPLIT, int FULLC, typename AT = float>
 __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
+    constexpr int AB = (int)sizeof(AT);
     constexpr int KCH = ATTN_KCH, NKG = 2 * KCH;
     __shared__ __attribute__((aligned(16))) u32x4 s_ah[NKG * 256];
     __shared__ __attribute__((aligned(16))) u32x4 s_al[NKG * 256];
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
     const int head = wg & 3, slice = (wg >> 2) % nsl, b = (wg >> 2) / nsl;
     const int tile0 = slice * a.tps;
     const int tile1 = min(tile0 + a.tps, a.tiles);
-    const float *xb = a.x + (size_t)b * a.C * a.HW;
+    const AT *xb = reinterpret_cast<const AT *>(a.x) + (size_t)b * a.C * a.HW;
     const u32x4 *wblk = reinterpret_cast<const u32x4 *>(a.wkv) + (size_t)head * a.nstage * (2 * NKG * 64);
 
     float raw[NKG][8];
@@ -67,19 +68,21 @@ __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
     const unsigned long long xaddr = reinterpret_cast<unsigned long long>(xb);
     const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xaddr);           // (unsigned: the builtin returns int and
     const unsigned xhi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));   //  would sign-extend into the high word)
-    const int xbytes = a.C * a.HW * 4;
+    const int xbytes = a.C * a.HW * AB;
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<void *>(((unsigned long long)xhi << 32) | xlo), 0, __builtin_amdgcn_readfirstlane(xbytes), 0x00020000);
     auto load = [&](int tile, int stage) {
         const int n = tile * 256 + tid;
-        const int voff = n < a.HW ? n * 4 : xbytes;
+        const int voff = n < a.HW ? n * AB : xbytes;
 #pragma unroll
         for (int kg = 0; kg < NKG; ++kg) {
             const int cb = stage * 16 * KCH + kg * 8;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int c = FULLC ? cb + i : min(cb + i, a.C - 1);
-                const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, voff, c * a.HW * 4, 0));
+                float v;
+                if constexpr (AB == 4) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, voff, c * a.HW * 4, 0));
+                else v = __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsx, voff, c * a.HW * 2, 0) << 16);
                 raw[kg][i] = (FULLC || cb + i < a.C) ? v : 0.f;
             }
         }
@@ -244,8 +247,8 @@ __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
     }
 }
 
-hipError_t launch_attn_ctx(const float *x, const unsigned char *wkv, float *partials, int B, int C, int HW, int nsplit,
-                           hipStream_t st) {
+hipError_t launch_attn_ctx(const void *x, const unsigned char *wkv, float *partials, int B, int C, int HW, int nsplit,
+                           hipStream_t st, int act_bf16) {
     AttnGeom g = attn_geom(HW);
     if ((size_t)C * HW * 4 >= ((size_t)1 << 31)) return hipErrorInvalidValue;     // 32-bit offsets in the buffer descriptor
     AttnCtxArgs a;
@@ -253,6 +256,12 @@ hipError_t launch_attn_ctx(const float *x, const unsigned char *wkv, float *part
     a.nstage = (C + 16 * ATTN_KCH - 1) / (16 * ATTN_KCH);
     a.tiles = g.tiles; a.tps = g.tps; a.nrec = g.nrec; a.nsplit = nsplit; a.B = B;
     const dim3 grid(g.nslices * 4 * B);
+    if (act_bf16) {
+        if (nsplit > 1) return hipErrorInvalidValue;
+        if (C % 32 == 0) hipLaunchKernelGGL((attn_ctx_kernel<1, 1, __bf16>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_ctx_kernel<1, 0, __bf16>), grid, dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
     if (C % 32 == 0) {
         if (nsplit > 1) hipLaunchKernelGGL((attn_ctx_kernel<2, 1>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((attn_ctx_kernel<1, 1>), grid, dim3(256), 0, st, a);

@@ -96,8 +96,8 @@ enum ConvEpi {
 
 struct ConvArgs {
     // input: channels [0,c0) come from src0, [c0,c0+c1) from src1 (torch.cat on dim 1 without the copy)
-    const float *src0;
-    const float *src1;
+    const void *src0;       // activation tensors are fp32 or (act_bf16) bf16
+    const void *src1;
     int c0, c1;
     int cin;            // c0 + c1
     int nchunk;         // ceil(cin / (16 * kch))   (set by launch_conv)
@@ -116,14 +116,15 @@ struct ConvArgs {
     size_t bias_bstride;
     int cout;
     int epi;
-    float *out;             // [B][cout][Hout][Wout]
+    void *out;              // [B][cout][Hout][Wout]
     float *partials;        // EPI_STATS: [B][nparts][groups][2]
     int nparts;
     int groups;
-    const float *eh;        // EPI_TAIL: h_raw [B][cout][Hout][Wout]
+    const void *eh;         // EPI_TAIL: h_raw [B][cout][Hout][Wout]
     const float *esc, *esh; // EPI_TAIL: [B][cout]
-    const float *eres;      // EPI_ATTN: residual [B][cout][Hout][Wout]
+    const void *eres;       // EPI_ATTN: residual [B][cout][Hout][Wout]
     int nsplit;             // 2: bf16x3 (hi/lo), 1: plain bf16
+    int act_bf16;           // 1: activation tensors are stored as bf16 (GTTS_PREC_BF16_STORE)
     int tiles_x, tiles_y;
 };
 

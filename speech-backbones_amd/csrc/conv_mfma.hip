@@ -78,6 +78,18 @@ extern "C" int gtts_debug_trace(unsigned long long *dst, int n) {
 
 namespace gtts {
 
+// activation load / store through a buffer descriptor (per-lane byte offset + scalar byte offset), fp32 or bf16 storage
+template <typename AT>
+__device__ __forceinline__ float ld_act(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    if constexpr (sizeof(AT) == 4) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+    else return __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0) << 16);
+}
+template <typename AT>
+__device__ __forceinline__ void st_act(float v, __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    if constexpr (sizeof(AT) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs, voff, soff, 0);
+    else __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (__bf16)v), rs, voff, soff, 0);
+}
+
 template <int MODE, int WM, int WN, int MF, int KCH>
 struct ConvCfg {
     static constexpr int MT = WM * MF * 32;
@@ -109,8 +121,11 @@ static inline size_t conv_smem_bytes(int npix, int nkg, int wblk16, int cin, int
 // channel padding and every chunk comes from one source.  Then all global loads are buffer loads -- per-lane byte
 // offset fixed per staging item, per-chunk/channel offset in an SGPR -- and need no VALU address arithmetic, and the
 // zero padding of the halo is produced by the mask factor alone (out-of-image items read offset 0 and get m = 0).
-template <int MODE, int WM, int WN, int MF, int KCH, int PRO, int EPI, int NSPLIT, int FULLC>
+// AT = storage type of the activation tensors (float, or __bf16 for the bf16-storage mode of BASELINE config 3: every
+// activation is read / written as bf16, the accumulators and the GroupNorm statistics stay fp32).
+template <int MODE, int WM, int WN, int MF, int KCH, int PRO, int EPI, int NSPLIT, int FULLC, typename AT>
 __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void conv_mfma_kernel(const ConvArgs a) {
+    constexpr int AB = (int)sizeof(AT);      // bytes per stored activation
     using C = ConvCfg<MODE, WM, WN, MF, KCH>;
     constexpr int MT = C::MT, TR = C::TR, TC = C::TC, NST = C::NST, TPS = C::TPS, NKG = C::NKG;
     constexpr int HC = C::HC, NPIX = C::NPIX, AITER = C::AITER, WBLK16 = C::WBLK16, WITER = C::WITER;
@@ -167,7 +182,7 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
         const int gy = iy0 + pr, gx = ix0 + pc;
         const bool in = has && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
         it_goff[it] = in ? gy * a.Win + gx : 0;
-        if (FULLC) it_goff[it] = (it_goff[it] + min(kg, NKG - 1) * 8 * HWin) * 4;
+        if (FULLC) it_goff[it] = (it_goff[it] + min(kg, NKG - 1) * 8 * HWin) * AB;
         float m = 1.f;
         if (PRO != PRO_PLAIN) m = a.mask[(size_t)b * a.T + ((size_t)(in ? gx : 0) << a.lvl_in)];
         it_m[it] = in ? m : -1.f;
@@ -178,8 +193,8 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
     // buffer descriptors (FULLC): built per chunk from wave-uniform scalars (readfirstlane keeps them in SGPRs --
     // a descriptor the compiler believes divergent is loaded through a waterfall loop)
     const int srcC0 = PRO == PRO_IGLU ? 2 * a.cin : a.c0;
-    const float *sbase0 = a.src0 + (size_t)b * srcC0 * HWin;
-    const float *sbase1 = a.c1 > 0 ? a.src1 + (size_t)b * a.c1 * HWin : sbase0;
+    const AT *sbase0 = reinterpret_cast<const AT *>(a.src0) + (size_t)b * srcC0 * HWin;
+    const AT *sbase1 = a.c1 > 0 ? reinterpret_cast<const AT *>(a.src1) + (size_t)b * a.c1 * HWin : sbase0;
     auto uniform_rsrc = [](const void *p, int bytes) {
         const unsigned long long u = reinterpret_cast<unsigned long long>(p);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
@@ -192,16 +207,15 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
             const int cb = chunk * (8 * NKG);
             const bool first = cb < a.c0 || PRO == PRO_IGLU;
             const __amdgpu_buffer_rsrc_t rs0 =
-                uniform_rsrc(first ? sbase0 : sbase1, (first ? srcC0 : a.c1) * HWin * 4);
-            const int soff = (first ? cb : cb - a.c0) * HWin * 4;
+                uniform_rsrc(first ? sbase0 : sbase1, (first ? srcC0 : a.c1) * HWin * AB);
+            const int soff = (first ? cb : cb - a.c0) * HWin * AB;
 #pragma unroll
             for (int it = 0; it < AITER; ++it) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const int so = soff + i * HWin * 4;
-                    araw[it][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs0, it_goff[it], so, 0));
-                    if (PRO == PRO_IGLU)
-                        brawst[it][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs0, it_goff[it], so + a.cin * HWin * 4, 0));
+                    const int so = soff + i * HWin * AB;
+                    araw[it][i] = ld_act<AT>(rs0, it_goff[it], so);
+                    if (PRO == PRO_IGLU) brawst[it][i] = ld_act<AT>(rs0, it_goff[it], so + a.cin * HWin * AB);
                 }
             }
             return;
@@ -213,16 +227,16 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
             const int cbase = chunk * (8 * NKG) + kg * 8;
             const int nval = min(max(a.cin - cbase, 0), 8);        // valid channels of this 8-group
             const int cb0 = nval > 0 ? cbase : 0;
-            const float *pl;
-            if (PRO == PRO_IGLU) pl = a.src0 + ((size_t)b * 2 * a.cin + cb0) * HWin;
-            else pl = (cb0 < a.c0) ? a.src0 + ((size_t)b * a.c0 + cb0) * HWin
-                                   : a.src1 + ((size_t)b * a.c1 + (cb0 - a.c0)) * HWin;
+            const AT *pl;
+            if (PRO == PRO_IGLU) pl = reinterpret_cast<const AT *>(a.src0) + ((size_t)b * 2 * a.cin + cb0) * HWin;
+            else pl = (cb0 < a.c0) ? reinterpret_cast<const AT *>(a.src0) + ((size_t)b * a.c0 + cb0) * HWin
+                                   : reinterpret_cast<const AT *>(a.src1) + ((size_t)b * a.c1 + (cb0 - a.c0)) * HWin;
             pl += it_goff[it];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int ii = min(i, max(nval, 1) - 1);            // clamp: always a valid address
-                araw[it][i] = pl[(size_t)ii * HWin];                 // zeroing of i >= nval happens at use
-                if (PRO == PRO_IGLU) brawst[it][i] = pl[(size_t)(ii + a.cin) * HWin];
+                araw[it][i] = (float)pl[(size_t)ii * HWin];          // zeroing of i >= nval happens at use
+                if (PRO == PRO_IGLU) brawst[it][i] = (float)pl[(size_t)(ii + a.cin) * HWin];
             }
         }
     };
@@ -476,10 +490,11 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
     // Output (and the fused-tail / residual input) go through buffer descriptors of this sample's tensors: per-lane
     // byte offset = pixel + the lane's 4-channel sub-row, per-channel offset in an SGPR -> no 64-bit VALU address
     // arithmetic per access.
-    const int out_bytes = a.cout * HWout * 4;
-    const __amdgpu_buffer_rsrc_t rs_out = uniform_rsrc(a.out + (size_t)b * a.cout * HWout, out_bytes);
-    const __amdgpu_buffer_rsrc_t rs_ex =
-        uniform_rsrc((EPI == EPI_TAIL ? a.eh : (EPI == EPI_ATTN ? a.eres : a.out)) + (size_t)b * a.cout * HWout, out_bytes);
+    const int out_bytes = a.cout * HWout * AB;
+    const __amdgpu_buffer_rsrc_t rs_out = uniform_rsrc(reinterpret_cast<AT *>(a.out) + (size_t)b * a.cout * HWout, out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_ex = uniform_rsrc(
+        reinterpret_cast<const AT *>(EPI == EPI_TAIL ? a.eh : (EPI == EPI_ATTN ? a.eres : (const void *)a.out)) + (size_t)b * a.cout * HWout,
+        out_bytes);
     const int ch0 = __builtin_amdgcn_readfirstlane(cot * MT + m0);     // first channel of this wave's fragments
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
@@ -490,15 +505,15 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
         if (pix_ok) {      // one exec-mask region per row; straight-line code inside
             float m_out = 0.f;
             if (EPI == EPI_TAIL) m_out = a.mask[(size_t)b * a.T + ((size_t)ox << a.lvl_out)];
-            const int voff = (oy * a.Wout + ox + 4 * kg_l * HWout) * 4;
+            const int voff = (oy * a.Wout + ox + 4 * kg_l * HWout) * AB;
 #pragma unroll
             for (int mi = 0; mi < MF; ++mi) {
                 float ex[16];
                 if (EPI == EPI_TAIL || EPI == EPI_ATTN) {
 #pragma unroll
                     for (int rg = 0; rg < 16; ++rg) {
-                        const int soff = (ch0 + mi * 32 + (rg & 3) + 8 * (rg >> 2)) * HWout * 4;
-                        ex[rg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ex, voff, soff, 0));
+                        const int soff = (ch0 + mi * 32 + (rg & 3) + 8 * (rg >> 2)) * HWout * AB;
+                        ex[rg] = ld_act<AT>(rs_ex, voff, soff);
                     }
                 }
 #pragma unroll
@@ -511,8 +526,8 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
                     } else if (EPI == EPI_ATTN) {
                         v += ex[rg];
                     }
-                    const int soff = (ch0 + mi * 32 + (rg & 3) + 8 * (rg >> 2)) * HWout * 4;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs_out, voff, soff, 0);
+                    const int soff = (ch0 + mi * 32 + (rg & 3) + 8 * (rg >> 2)) * HWout * AB;
+                    st_act<AT>(v, rs_out, voff, soff);
                     if (EPI == EPI_STATS) {
                         // octet rg>>2 of this 32-channel fragment (static index); octets -> groups below
                         st1[mi][rg >> 2] += v;
@@ -588,7 +603,7 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void c
 }
 
 
-template <int MODE, int WM, int WN, int MF, int KCH, int PRO, int EPI, int NSPLIT, int FULLC>
+template <int MODE, int WM, int WN, int MF, int KCH, int PRO, int EPI, int NSPLIT, int FULLC, typename AT = float>
 static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
     using C = ConvCfg<MODE, WM, WN, MF, KCH>;
     ConvArgs a = a_in;
@@ -603,7 +618,7 @@ static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
     // buffer descriptors address one sample's tensor with 32-bit byte offsets
     const size_t lim = (size_t)1 << 31;
     const size_t in_c = (size_t)(PRO == PRO_IGLU ? 2 * a.cin : std::max(a.c0, a.c1));
-    if (in_c * a.Hin * a.Win * 4 >= lim || (size_t)a.cout * a.Hout * a.Wout * 4 >= lim) return hipErrorInvalidValue;
+    if (in_c * a.Hin * a.Win * sizeof(AT) >= lim || (size_t)a.cout * a.Hout * a.Wout * sizeof(AT) >= lim) return hipErrorInvalidValue;
     size_t smem = conv_smem_bytes(C::NPIX, C::NKG, C::WBLK16, a.cin, PRO, C::MT) +
                   (ConvWdma<MODE, WM, FULLC>::on ? (size_t)C::WBLK16 * 16 : 0);
     // hipFuncSetAttribute is per device: remember the largest size set on each device (atomics: launches may come
@@ -613,12 +628,12 @@ static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (smem > attr_set[dev].load(std::memory_order_relaxed)) {
         hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&conv_mfma_kernel<MODE, WM, WN, MF, KCH, PRO, EPI, NSPLIT, FULLC>),
+            reinterpret_cast<const void *>(&conv_mfma_kernel<MODE, WM, WN, MF, KCH, PRO, EPI, NSPLIT, FULLC, AT>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr_set[dev].store(smem, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, MF, KCH, PRO, EPI, NSPLIT, FULLC>), grid, dim3(256), smem, st, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, MF, KCH, PRO, EPI, NSPLIT, FULLC, AT>), grid, dim3(256), smem, st, a);
     return hipGetLastError();
 }
 
@@ -636,6 +651,15 @@ static hipError_t launch_prec(const ConvArgs &a, hipStream_t st) {
     const bool fullc = a.cin % 16 == 0 && (a.c1 == 0 || a.c0 % 16 == 0);
     // ragged channel counts only occur on first layers (stacked input, 1-channel reference): PRO_MASK variants
     constexpr bool ragged_ok = PRO == PRO_MASK && (MODE == CONV_C3 || MODE == CONV_P1);
+    if (a.act_bf16) {
+        // bf16 storage (BASELINE config 3): single-pass bf16 MFMA only, Grad-TTS op set only (no InstanceNorm-GLU convs)
+        if constexpr (PRO != PRO_IGLU && !(MODE == CONV_C3 && EPI == EPI_PLAIN)) {
+            if (a.nsplit > 1) return hipErrorInvalidValue;
+            if (fullc) return launch_cfg<MODE, WM, WN, MF, 1, PRO, EPI, 1, 1, __bf16>(a, st);
+            if constexpr (ragged_ok) return launch_cfg<MODE, WM, WN, MF, 1, PRO, EPI, 1, 0, __bf16>(a, st);
+        }
+        return hipErrorInvalidValue;
+    }
     if (fullc)
         return a.nsplit > 1 ? launch_cfg<MODE, WM, WN, MF, 1, PRO, EPI, 2, 1>(a, st)
                             : launch_cfg<MODE, WM, WN, MF, 1, PRO, EPI, 1, 1>(a, st);

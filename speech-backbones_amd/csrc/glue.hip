@@ -79,4 +79,58 @@ hipError_t launch_expand_alignment(const float *dur, const float *x_mask, const 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ log_prior
+// Gaussian log-likelihood of every (token, frame) pair, the score matrix MAS walks (Grad-TTS/model/tts.py:130-139):
+//   log_prior[b, i, j] = sum_f -0.5 y[f,j]^2 + sum_f mu_x[f,i] y[f,j] + sum_f -0.5 mu_x[f,i]^2 - 0.5 log(2 pi) F
+// The reference builds it from three dense [t_x,F]x[F,T] matmuls and two broadcast adds; here one workgroup owns a
+// 16-token x 64-frame tile, stages both operand tiles in LDS once and evaluates the same quantity as
+// -0.5 sum_f (y - mu)^2 + const (no cancellation between the three large terms).  Output feeds gtts_mas_maximum_path
+// directly on the device.
+__global__ __launch_bounds__(256) void log_prior_kernel(const float *__restrict__ mu_x, const float *__restrict__ y,
+                                                        float *__restrict__ out, int F, int tx, int T, float cst) {
+    extern __shared__ float sm[];          // [F][64] frames, then [F][16] tokens
+    float *s_y = sm, *s_mu = sm + (size_t)F * 64;
+    const int b = blockIdx.z, i0 = blockIdx.y * 16, j0 = blockIdx.x * 64, tid = threadIdx.x;
+    const float *yb = y + (size_t)b * F * T, *mb = mu_x + (size_t)b * F * tx;
+    for (int e = tid; e < F * 64; e += 256) {
+        const int f = e >> 6, j = j0 + (e & 63);
+        s_y[e] = j < T ? yb[(size_t)f * T + j] : 0.f;
+    }
+    for (int e = tid; e < F * 16; e += 256) {
+        const int f = e >> 4, i = i0 + (e & 15);
+        s_mu[e] = i < tx ? mb[(size_t)f * tx + i] : 0.f;
+    }
+    __syncthreads();
+    const int jl = tid & 63, ig = tid >> 6;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < F; ++f) {
+        const float yv = s_y[f * 64 + jl];
+        const float4 m4 = *reinterpret_cast<const float4 *>(s_mu + f * 16 + ig * 4);
+        const float d0 = yv - m4.x, d1 = yv - m4.y, d2 = yv - m4.z, d3 = yv - m4.w;
+        acc[0] = fmaf(d0, d0, acc[0]); acc[1] = fmaf(d1, d1, acc[1]);
+        acc[2] = fmaf(d2, d2, acc[2]); acc[3] = fmaf(d3, d3, acc[3]);
+    }
+    const int j = j0 + jl;
+    if (j < T) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + ig * 4 + k;
+            if (i < tx) out[((size_t)b * tx + i) * T + j] = fmaf(-0.5f, acc[k], cst);
+        }
+    }
+}
+
+hipError_t launch_log_prior(const float *mu_x, const float *y, float *out, int B, int F, int tx, int T, hipStream_t st) {
+    const size_t smem = (size_t)F * 80 * sizeof(float);
+    if (smem > 160 * 1024) return hipErrorInvalidValue;
+    if (smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&log_prior_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+    }
+    const float cst = (float)(-0.5 * 1.8378770664093453 * (double)F);     // -0.5 * log(2 pi) * n_feats
+    hipLaunchKernelGGL(log_prior_kernel, dim3((T + 63) / 64, (tx + 15) / 16, B), dim3(256), smem, st, mu_x, y, out, F, tx, T, cst);
+    return hipGetLastError();
+}
+
 }  // namespace gtts

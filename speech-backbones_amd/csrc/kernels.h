@@ -26,22 +26,23 @@ struct VcStep {
     float sigma;
 };
 
-hipError_t launch_prep_input(const float *mu, const float *x, const float *s, float *x0, int B, int F, int T,
-                             int nch, hipStream_t st);
+hipError_t launch_prep_input(const float *mu, const float *x, const float *s, void *x0, int B, int F, int T,
+                             int nch, hipStream_t st, int act_bf16 = 0);
 hipError_t launch_spk_mlp(const float *spk, const float *w0, const float *b0, const float *w2, const float *b2,
                           float *s, int B, int E, int F, hipStream_t st);
 hipError_t launch_time_mlp(const float *t, const float *freq, float pe_scale, const unsigned char *blob,
                            const TimeMlpDesc &d, float *tb, int rows, hipStream_t st);
 hipError_t launch_gn_finalize(const float *partials, int nparts, int groups, int C, int HW, const float *gamma,
                               const float *beta, float *sc, float *sh, int B, hipStream_t st);
-hipError_t launch_tail_identity(const float *h, const float *x, const float *sc, const float *sh, const float *mask,
-                                float *out, int B, int C, int H, int W, int T, int lvl, hipStream_t st);
+hipError_t launch_tail_identity(const void *h, const void *x, const float *sc, const float *sh, const float *mask,
+                                void *out, int B, int C, int H, int W, int T, int lvl, hipStream_t st, int act_bf16 = 0);
 hipError_t launch_euler_step(float *xt, const float *mu, const float *est, const float *mask, const float *noise,
                              float beta, float h, int B, int F, int T, hipStream_t st);
 hipError_t launch_mul_mask(const float *z, const float *mask, float *out, int B, int F, int T, hipStream_t st);
-hipError_t launch_final_euler(const float *raw, const float *sc, const float *sh, const float *w, const float *bias,
+hipError_t launch_final_euler(const void *raw, const float *sc, const float *sh, const float *w, const float *bias,
                               const float *mask, int B, int C, int F, int T, float *est_out, float *xt, const float *mu,
-                              const float *noise, float beta, float h, hipStream_t st, const VcStep *vc = nullptr);
+                              const float *noise, float beta, float h, hipStream_t st, const VcStep *vc = nullptr,
+                              int act_bf16 = 0);
 
 // ---- vc.hip  (DiffVC-only pieces: RefBlock statistics / pooling, condition MLP, input assembly)
 hipError_t launch_xt_ref(const float *ref, const float *mean_ref, const float *ref_mask, float *out, float w0, float w1,
@@ -82,8 +83,8 @@ static inline size_t attn_kv_packed_bytes(int C) {      // [head 4][stage][split
     size_t nstage = (C + 16 * ATTN_KCH - 1) / (16 * ATTN_KCH);
     return 4 * nstage * 2 * (2 * ATTN_KCH) * 64 * 16;
 }
-hipError_t launch_attn_ctx(const float *x, const unsigned char *wkv, float *partials, int B, int C, int HW, int nsplit,
-                           hipStream_t st);
+hipError_t launch_attn_ctx(const void *x, const unsigned char *wkv, float *partials, int B, int C, int HW, int nsplit,
+                           hipStream_t st, int act_bf16 = 0);
 hipError_t launch_attn_merge(const float *partials, float *ctxn, int B, int nrec, hipStream_t st);
 // wq [128][C], wout [C][128], bout [C], g [1] fp32 (reference layouts) -> per-sample packed 1x1 weights + bias
 hipError_t launch_attn_fold(const float *ctxn, const float *wq, const float *wout, const float *bout, const float *g,
@@ -98,6 +99,8 @@ hipError_t launch_copy_f32(const float *src, float *dst, size_t n, hipStream_t s
 hipError_t launch_expand_alignment(const float *dur, const float *x_mask, const int *y_len, const float *mu_x,
                                    const float *noise, float temperature, float *attn, float *mu_y, float *z, int B, int F,
                                    int tx, int T, hipStream_t st);
+
+hipError_t launch_log_prior(const float *mu_x, const float *y, float *out, int B, int F, int tx, int T, hipStream_t st);
 
 // ---- mas.hip
 hipError_t launch_mas(const float *value, const float *mask, const int *t_x, const int *t_y, int *path,

@@ -12,8 +12,9 @@
 namespace gtts {
 
 // ------------------------------------------------------------------------------------------------ prep_input
+template <typename AT>
 __global__ void prep_input_kernel(const float *__restrict__ mu, const float *__restrict__ x,
-                                  const float *__restrict__ s, float *__restrict__ x0, int F, int T, int nch) {
+                                  const float *__restrict__ s, AT *__restrict__ x0, int F, int T, int nch) {
     // grid: (ceil(F*T/256), nch, B)
     const int b = blockIdx.z, c = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -22,13 +23,14 @@ __global__ void prep_input_kernel(const float *__restrict__ mu, const float *__r
     if (c == 0) v = mu[(size_t)b * F * T + i];
     else if (c == 1) v = x[(size_t)b * F * T + i];
     else v = s[(size_t)b * F + i / T];     // speaker channel: constant along frames (diffusion.py:184)
-    x0[((size_t)b * nch + c) * F * T + i] = v;
+    x0[((size_t)b * nch + c) * F * T + i] = (AT)v;
 }
 
-hipError_t launch_prep_input(const float *mu, const float *x, const float *s, float *x0, int B, int F, int T,
-                             int nch, hipStream_t st) {
+hipError_t launch_prep_input(const float *mu, const float *x, const float *s, void *x0, int B, int F, int T,
+                             int nch, hipStream_t st, int act_bf16) {
     dim3 grid((F * T + 255) / 256, nch, B);
-    hipLaunchKernelGGL(prep_input_kernel, grid, dim3(256), 0, st, mu, x, s, x0, F, T, nch);
+    if (act_bf16) hipLaunchKernelGGL(prep_input_kernel<__bf16>, grid, dim3(256), 0, st, mu, x, s, (__bf16 *)x0, F, T, nch);
+    else hipLaunchKernelGGL(prep_input_kernel<float>, grid, dim3(256), 0, st, mu, x, s, (float *)x0, F, T, nch);
     return hipGetLastError();
 }
 
@@ -160,10 +162,25 @@ hipError_t launch_gn_finalize(const float *partials, int nparts, int groups, int
 }
 
 // ------------------------------------------------------------------------------------------------ tail_identity
-template <int VEC>
-__global__ void tail_identity_kernel(const float *__restrict__ h, const float *__restrict__ x,
+// 4 consecutive activations as fp32, from fp32 or bf16 storage
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 ld4(const __bf16 *p) {
+    const uint2 u = *reinterpret_cast<const uint2 *>(p);
+    return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                       __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ void st4(__bf16 *p, float4 v) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    bf16x4 o;
+    o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+    *reinterpret_cast<bf16x4 *>(p) = o;
+}
+
+template <int VEC, typename AT>
+__global__ void tail_identity_kernel(const AT *__restrict__ h, const AT *__restrict__ x,
                                      const float *__restrict__ sc, const float *__restrict__ sh,
-                                     const float *__restrict__ mask, float *__restrict__ out, int C, int H, int W,
+                                     const float *__restrict__ mask, AT *__restrict__ out, int C, int H, int W,
                                      int T, int lvl) {
     // grid: (ceil(H*W/VEC/256), C, B): one (sample, channel) plane per blockIdx.(y,z) -> scalar scale/shift
     const int b = blockIdx.z, c = blockIdx.y;
@@ -173,8 +190,8 @@ __global__ void tail_identity_kernel(const float *__restrict__ h, const float *_
     const size_t base = ((size_t)b * C + c) * H * W + i;
     const int col = i % W;
     if (VEC == 4) {
-        const float4 hv = *reinterpret_cast<const float4 *>(h + base);
-        const float4 xv = *reinterpret_cast<const float4 *>(x + base);
+        const float4 hv = ld4(h + base);
+        const float4 xv = ld4(x + base);
         const float *mp = mask + (size_t)b * T;
         const float m0 = mp[(size_t)(col + 0) << lvl], m1 = mp[(size_t)(col + 1) << lvl];
         const float m2 = mp[(size_t)(col + 2) << lvl], m3 = mp[(size_t)(col + 3) << lvl];
@@ -183,23 +200,29 @@ __global__ void tail_identity_kernel(const float *__restrict__ h, const float *_
         o.y = mish_f(hv.y * a + s) * m1 + xv.y * m1;
         o.z = mish_f(hv.z * a + s) * m2 + xv.z * m2;
         o.w = mish_f(hv.w * a + s) * m3 + xv.w * m3;
-        *reinterpret_cast<float4 *>(out + base) = o;
+        st4(out + base, o);
     } else {
         const float m = mask[(size_t)b * T + ((size_t)col << lvl)];
-        out[base] = mish_f(h[base] * a + s) * m + x[base] * m;
+        out[base] = (AT)(mish_f((float)h[base] * a + s) * m + (float)x[base] * m);
     }
 }
 
-hipError_t launch_tail_identity(const float *h, const float *x, const float *sc, const float *sh, const float *mask,
-                                float *out, int B, int C, int H, int W, int T, int lvl, hipStream_t st) {
+template <typename AT>
+static hipError_t launch_tail_identity_t(const AT *h, const AT *x, const float *sc, const float *sh, const float *mask,
+                                         AT *out, int B, int C, int H, int W, int T, int lvl, hipStream_t st) {
     if (W % 4 == 0) {
         dim3 grid((H * W / 4 + 255) / 256, C, B);
-        hipLaunchKernelGGL(tail_identity_kernel<4>, grid, dim3(256), 0, st, h, x, sc, sh, mask, out, C, H, W, T, lvl);
+        hipLaunchKernelGGL((tail_identity_kernel<4, AT>), grid, dim3(256), 0, st, h, x, sc, sh, mask, out, C, H, W, T, lvl);
     } else {
         dim3 grid((H * W + 255) / 256, C, B);
-        hipLaunchKernelGGL(tail_identity_kernel<1>, grid, dim3(256), 0, st, h, x, sc, sh, mask, out, C, H, W, T, lvl);
+        hipLaunchKernelGGL((tail_identity_kernel<1, AT>), grid, dim3(256), 0, st, h, x, sc, sh, mask, out, C, H, W, T, lvl);
     }
     return hipGetLastError();
+}
+hipError_t launch_tail_identity(const void *h, const void *x, const float *sc, const float *sh, const float *mask,
+                                void *out, int B, int C, int H, int W, int T, int lvl, hipStream_t st, int act_bf16) {
+    if (act_bf16) return launch_tail_identity_t((const __bf16 *)h, (const __bf16 *)x, sc, sh, mask, (__bf16 *)out, B, C, H, W, T, lvl, st);
+    return launch_tail_identity_t((const float *)h, (const float *)x, sc, sh, mask, (float *)out, B, C, H, W, T, lvl, st);
 }
 
 // ------------------------------------------------------------------------------------------------ Euler update
@@ -275,7 +298,8 @@ __device__ __forceinline__ float vc_update(float xt, float mean, float est, floa
     return __fmul_rn(__fsub_rn(xt, dxt), m);
 }
 
-__global__ void final_euler_kernel(const float *__restrict__ raw, const float *__restrict__ sc,
+template <typename AT>
+__global__ void final_euler_kernel(const AT *__restrict__ raw, const float *__restrict__ sc,
                                    const float *__restrict__ sh, const float *__restrict__ w, const float *__restrict__ bias,
                                    const float *__restrict__ mask, int C, int F, int T, float *__restrict__ est_out,
                                    float *__restrict__ xt, const float *__restrict__ mu, const float *__restrict__ noise,
@@ -293,10 +317,10 @@ __global__ void final_euler_kernel(const float *__restrict__ raw, const float *_
     if (i >= FT) return;
     const int col = i % T;
     const float m = mask[(size_t)b * T + col];
-    const float *p = raw + (size_t)b * C * FT + i;
+    const AT *p = raw + (size_t)b * C * FT + i;
     float acc = 0.f;
     for (int c = 0; c < C; ++c) {
-        const float v = mish_f(p[(size_t)c * FT] * sm[c] + sm[C + c]) * m * m;
+        const float v = mish_f((float)p[(size_t)c * FT] * sm[c] + sm[C + c]) * m * m;
         acc = fmaf(sm[2 * C + c], v, acc);
     }
     const float est = (acc + bias[0]) * m;
@@ -308,16 +332,20 @@ __global__ void final_euler_kernel(const float *__restrict__ raw, const float *_
     }
 }
 
-hipError_t launch_final_euler(const float *raw, const float *sc, const float *sh, const float *w, const float *bias,
+hipError_t launch_final_euler(const void *raw, const float *sc, const float *sh, const float *w, const float *bias,
                               const float *mask, int B, int C, int F, int T, float *est_out, float *xt, const float *mu,
-                              const float *noise, float beta, float h, hipStream_t st, const VcStep *vc) {
+                              const float *noise, float beta, float h, hipStream_t st, const VcStep *vc, int act_bf16) {
     dim3 grid((F * T + 255) / 256, B);
     const float sq = sqrtf(beta * h);
     VcStep v;
     v.mode = 0; v.cm = v.k1 = v.bh = v.sigma = 0.f;
     if (vc) v = *vc;
-    hipLaunchKernelGGL(final_euler_kernel, grid, dim3(256), (size_t)3 * C * sizeof(float), st, raw, sc, sh, w, bias,
-                       mask, C, F, T, est_out, xt, mu, noise, beta, h, sq, v);
+    if (act_bf16)
+        hipLaunchKernelGGL(final_euler_kernel<__bf16>, grid, dim3(256), (size_t)3 * C * sizeof(float), st, (const __bf16 *)raw, sc, sh,
+                           w, bias, mask, C, F, T, est_out, xt, mu, noise, beta, h, sq, v);
+    else
+        hipLaunchKernelGGL(final_euler_kernel<float>, grid, dim3(256), (size_t)3 * C * sizeof(float), st, (const float *)raw, sc, sh,
+                           w, bias, mask, C, F, T, est_out, xt, mu, noise, beta, h, sq, v);
     return hipGetLastError();
 }
 

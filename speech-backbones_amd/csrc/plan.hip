@@ -116,6 +116,11 @@ struct gtts_plan {
     int nsub = 0;
     hipStream_t sub[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    // hipGraph replay of whole sampler calls (gtts_plan_set_graph): one instantiated graph per distinct argument tuple
+    bool graph_on = false;
+    struct GraphRec { std::vector<unsigned long long> key; hipGraph_t graph; hipGraphExec_t exec; unsigned long long used; };
+    std::vector<GraphRec> graphs;
+    unsigned long long graph_clock = 0;
     // Execution state below (layout cache, profiling record) is mutated by the enqueueing calls: they take this
     // mutex for the duration of the (host-side, asynchronous) enqueue, so one plan may be shared by several host
     // threads / streams as long as each call brings its own workspace.
@@ -322,7 +327,10 @@ extern "C" int gtts_plan_create(const gtts_unet_cfg *cfg, gtts_plan **out) {
     if (cfg->dim <= 0 || cfg->dim % 32 != 0) return fail(GTTS_E_CONFIG, "dim must be a positive multiple of 32 (got %d)", cfg->dim);
     if (cfg->n_feats <= 0 || cfg->n_feats % 4 != 0) return fail(GTTS_E_CONFIG, "n_feats must be a multiple of 4 (got %d)", cfg->n_feats);
     if (cfg->groups != 8) return fail(GTTS_E_CONFIG, "only groups == 8 is supported (got %d)", cfg->groups);
-    if (cfg->precision != GTTS_PREC_BF16X3 && cfg->precision != GTTS_PREC_BF16) return fail(GTTS_E_CONFIG, "unknown precision %d", cfg->precision);
+    if (cfg->precision != GTTS_PREC_BF16X3 && cfg->precision != GTTS_PREC_BF16 && cfg->precision != GTTS_PREC_BF16_STORE)
+        return fail(GTTS_E_CONFIG, "unknown precision %d", cfg->precision);
+    if (cfg->precision == GTTS_PREC_BF16_STORE && cfg->arch != 0)
+        return fail(GTTS_E_CONFIG, "bf16 activation storage is implemented for the Grad-TTS decoder (arch 0) only");
     if (cfg->n_spks < 1) return fail(GTTS_E_CONFIG, "n_spks must be >= 1");
     gtts_plan *p = new gtts_plan();
     p->cfg = *cfg;
@@ -509,6 +517,7 @@ extern "C" void gtts_plan_destroy(gtts_plan *plan) {
     for (int h = 0; h < 4; ++h)
         if (plan->ev_join[h]) (void)hipEventDestroy(plan->ev_join[h]);      // the side streams belong to the caller
     if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
+    for (auto &g : plan->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
     for (auto &e : plan->prof_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &r : plan->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     delete plan;
@@ -618,7 +627,7 @@ static size_t tensor_bytes(const gtts_plan *p, const Tensor &t, int B, int T, in
     const int F = p->cfg.n_feats;
     const size_t H = (size_t)F >> t.lvl, W = (size_t)(t.tref ? Tr : T) >> t.lvl;
     switch (t.kind) {
-        case TK_ACT: return (size_t)B * t.C * H * W * 4;
+        case TK_ACT: return (size_t)B * t.C * H * W * (p->cfg.precision == GTTS_PREC_BF16_STORE ? 2 : 4);
         case TK_PERB: return (size_t)B * t.C * 4;
         case TK_PART: return (size_t)B * conv_nparts(t.mode, t.cout, (int)H, (int)W) * t.C * 2 * 4;
         case TK_APART: return (size_t)B * 4 * attn_geom((int)(H * W)).nrec * ATTN_REC * 4;
@@ -760,7 +769,8 @@ static inline float *tptr(const RunCtx &c, int id) { return id < 0 ? nullptr : (
 
 static int run_ops(const RunCtx &c) {
     gtts_plan *p = c.p;
-    const int F = p->cfg.n_feats, nsplit = p->cfg.precision == GTTS_PREC_BF16 ? 1 : 2;
+    const int F = p->cfg.n_feats, nsplit = p->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1;
+    const int abf = p->cfg.precision == GTTS_PREC_BF16_STORE ? 1 : 0;
     for (size_t oi = 0; oi < p->ops.size(); ++oi) {
         const Op &o = p->ops[oi];
         ProfScope prof_scope(p, c.st, (int)oi);
@@ -796,6 +806,7 @@ static int run_ops(const RunCtx &c) {
                 a.groups = p->cfg.groups;
                 a.eh = tptr(c, o.eh); a.esc = tptr(c, o.esc); a.esh = tptr(c, o.esh); a.eres = tptr(c, o.eres);
                 a.nsplit = nsplit;
+                a.act_bf16 = abf;
                 hipError_t e = launch_conv(o.mode, a, c.st);
                 if (e != hipSuccess) return fail(GTTS_E_HIP, "conv %s: %s", o.label.c_str(), hipGetErrorString(e));
                 break;
@@ -815,13 +826,13 @@ static int run_ops(const RunCtx &c) {
             case OP_TAILID: {
                 const int H = F >> o.lvl_in, W = c.T >> o.lvl_in;
                 hipError_t e = launch_tail_identity(tptr(c, o.eh), tptr(c, o.src0), tptr(c, o.esc), tptr(c, o.esh), c.mask,
-                                                    tptr(c, o.out), c.B, o.C, H, W, c.T, o.lvl_in, c.st);
+                                                    tptr(c, o.out), c.B, o.C, H, W, c.T, o.lvl_in, c.st, abf);
                 if (e != hipSuccess) return fail(GTTS_E_HIP, "tail %s: %s", o.label.c_str(), hipGetErrorString(e));
                 break;
             }
             case OP_ACTX: {
                 const int HW = (F >> o.lvl_in) * (c.T >> o.lvl_in);
-                hipError_t e = launch_attn_ctx(tptr(c, o.src0), c.blob + o.wkv_off, tptr(c, o.apart), c.B, o.C, HW, nsplit, c.st);
+                hipError_t e = launch_attn_ctx(tptr(c, o.src0), c.blob + o.wkv_off, tptr(c, o.apart), c.B, o.C, HW, nsplit, c.st, abf);
                 if (e != hipSuccess) return fail(GTTS_E_HIP, "attn_ctx %s: %s", o.label.c_str(), hipGetErrorString(e));
                 break;
             }
@@ -918,12 +929,12 @@ extern "C" int gtts_estimator_forward(gtts_plan *plan, const void *packed, const
     { ProfScope ps_(p, st, (int)p->ops.size() + XOP_TIME); HIPCHK(launch_time_mlp(t, (const float *)(blob + p->freq_off), p->cfg.pe_scale, blob, p->tmlp, tb, B, st)); }
     c.tb_row = tb;
     c.tb_bstride = p->tmlp.tb_stride;
-    { ProfScope ps_(p, st, (int)p->ops.size() + XOP_PREP); HIPCHK(launch_prep_input(mu, x, s, tptr(c, p->t_x0), B, F, T, p->cin0, st)); }
+    { ProfScope ps_(p, st, (int)p->ops.size() + XOP_PREP); HIPCHK(launch_prep_input(mu, x, s, tptr(c, p->t_x0), B, F, T, p->cin0, st, p->cfg.precision == GTTS_PREC_BF16_STORE)); }
     rc = run_ops(c);
     if (rc) return rc;
     { ProfScope ps_(p, st, (int)p->ops.size() + XOP_FINAL); HIPCHK(launch_final_euler(tptr(c, p->t_final_raw), tptr(c, p->t_final_sc), tptr(c, p->t_final_sh),
                               (const float *)(blob + p->fw_off), (const float *)(blob + p->fb_off), mask, B, p->cfg.dim, F, T,
-                              out, nullptr, nullptr, nullptr, 0.f, 0.f, st)); }
+                              out, nullptr, nullptr, nullptr, 0.f, 0.f, st, nullptr, p->cfg.precision == GTTS_PREC_BF16_STORE)); }
     return GTTS_OK;
 }
 
@@ -935,22 +946,12 @@ extern "C" int gtts_euler_step(float *xt, const float *mu, const float *est, con
     return GTTS_OK;
 }
 
-extern "C" int gtts_reverse_diffusion(gtts_plan *plan, const void *packed, const float *z, const float *mask,
-                                      const float *mu, const float *spk, const float *noise, float *out, void *workspace,
-                                      size_t workspace_bytes, int B, int T, int n_timesteps, int step_begin, int step_end,
-                                      gtts_stream_t stream) {
-    int rc = check_shape(plan, B, T);
-    if (rc) return rc;
-    if (!packed || !z || !mask || !mu || !out || !workspace) return fail(GTTS_E_NULL, "gtts_reverse_diffusion: null argument");
-    if (n_timesteps <= 0 || n_timesteps > 4096) return fail(GTTS_E_SHAPE, "n_timesteps must be in [1, 4096], got %d", n_timesteps);
-    if (step_begin < 0 || step_end > n_timesteps || step_begin >= step_end)
-        return fail(GTTS_E_SHAPE, "step range [%d, %d) is not inside [0, %d)", step_begin, step_end, n_timesteps);
-    if (plan->cfg.arch != 0) return fail(GTTS_E_CONFIG, "gtts_reverse_diffusion needs a Grad-TTS plan (arch 0); use gtts_vc_reverse_diffusion");
-    gtts_plan *p = plan;
-    std::lock_guard<std::mutex> lk(p->mu);
+// enqueue one sampler call (caller holds p->mu and has validated the arguments)
+static int enqueue_reverse_diffusion(gtts_plan *p, const void *packed, const float *z, const float *mask, const float *mu,
+                                     const float *spk, const float *noise, float *out, void *workspace, size_t workspace_bytes,
+                                     int B, int T, int n_timesteps, int step_begin, int step_end, hipStream_t st) {
+    int rc = GTTS_OK;
     const bool multi = p->cfg.n_spks > 1;
-    if (multi && !spk) return fail(GTTS_E_NULL, "multi-speaker plan needs spk");
-    hipStream_t st = (hipStream_t)stream;
     const unsigned char *blob = (const unsigned char *)packed;
     const int F = p->cfg.n_feats, N = n_timesteps, E = p->cfg.spk_emb_dim;
 
@@ -1013,13 +1014,13 @@ extern "C" int gtts_reverse_diffusion(gtts_plan *plan, const void *packed, const
                 const size_t off = (size_t)H.b0 * F * T;
                 H.c.tb_row = tb + (size_t)i * p->tmlp.tb_stride;
                 H.c.tb_bstride = 0;
-                { ProfScope ps_(p, H.c.st, (int)p->ops.size() + XOP_PREP); HIPCHK(launch_prep_input(mu + off, out + off, H.s, tptr(H.c, p->t_x0), H.c.B, F, T, p->cin0, H.c.st)); }
+                { ProfScope ps_(p, H.c.st, (int)p->ops.size() + XOP_PREP); HIPCHK(launch_prep_input(mu + off, out + off, H.s, tptr(H.c, p->t_x0), H.c.B, F, T, p->cin0, H.c.st, p->cfg.precision == GTTS_PREC_BF16_STORE)); }
                 const int rc2 = run_ops(H.c);
                 if (rc2) return rc2;
                 const float *nz = noise ? noise + (size_t)(i - step_begin) * B * F * T + off : nullptr;
                 { ProfScope ps_(p, H.c.st, (int)p->ops.size() + XOP_FINAL); HIPCHK(launch_final_euler(tptr(H.c, p->t_final_raw), tptr(H.c, p->t_final_sc), tptr(H.c, p->t_final_sh),
                                           (const float *)(blob + p->fw_off), (const float *)(blob + p->fb_off), H.c.mask, H.c.B, p->cfg.dim, F, T,
-                                          nullptr, out + off, mu + off, nz, beta, h, H.c.st)); }
+                                          nullptr, out + off, mu + off, nz, beta, h, H.c.st, nullptr, p->cfg.precision == GTTS_PREC_BF16_STORE)); }
             }
         }
         return GTTS_OK;
@@ -1036,6 +1037,73 @@ extern "C" int gtts_reverse_diffusion(gtts_plan *plan, const void *packed, const
         }
     }
     return rc;
+}
+
+
+extern "C" int gtts_plan_set_graph(gtts_plan *plan, int on) {
+    if (!plan) return fail(GTTS_E_NULL, "null plan");
+    std::lock_guard<std::mutex> lk(plan->mu);
+    plan->graph_on = on != 0;
+    if (!on) {
+        for (auto &g : plan->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+        plan->graphs.clear();
+    }
+    return GTTS_OK;
+}
+
+extern "C" int gtts_reverse_diffusion(gtts_plan *plan, const void *packed, const float *z, const float *mask,
+                                      const float *mu, const float *spk, const float *noise, float *out, void *workspace,
+                                      size_t workspace_bytes, int B, int T, int n_timesteps, int step_begin, int step_end,
+                                      gtts_stream_t stream) {
+    int rc = check_shape(plan, B, T);
+    if (rc) return rc;
+    if (!packed || !z || !mask || !mu || !out || !workspace) return fail(GTTS_E_NULL, "gtts_reverse_diffusion: null argument");
+    if (n_timesteps <= 0 || n_timesteps > 4096) return fail(GTTS_E_SHAPE, "n_timesteps must be in [1, 4096], got %d", n_timesteps);
+    if (step_begin < 0 || step_end > n_timesteps || step_begin >= step_end)
+        return fail(GTTS_E_SHAPE, "step range [%d, %d) is not inside [0, %d)", step_begin, step_end, n_timesteps);
+    if (plan->cfg.arch != 0) return fail(GTTS_E_CONFIG, "gtts_reverse_diffusion needs a Grad-TTS plan (arch 0); use gtts_vc_reverse_diffusion");
+    gtts_plan *p = plan;
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (p->cfg.n_spks > 1 && !spk) return fail(GTTS_E_NULL, "multi-speaker plan needs spk");
+    hipStream_t st = (hipStream_t)stream;
+    if (!p->graph_on || p->prof_on)
+        return enqueue_reverse_diffusion(p, packed, z, mask, mu, spk, noise, out, workspace, workspace_bytes, B, T, n_timesteps,
+                                         step_begin, step_end, st);
+
+    // ---- hipGraph replay (small-batch, launch-bound regime): the ~95 launches per Euler step of a call are captured
+    // once per distinct argument tuple (every device pointer is baked into the kernel nodes) and replayed with one
+    // hipGraphLaunch afterwards.  The graph holds pointers to caller memory only; nothing is allocated on the device.
+    std::vector<unsigned long long> key = {(unsigned long long)packed, (unsigned long long)z, (unsigned long long)mask,
+                                           (unsigned long long)mu, (unsigned long long)spk, (unsigned long long)noise,
+                                           (unsigned long long)out, (unsigned long long)workspace, (unsigned long long)workspace_bytes,
+                                           (unsigned long long)B, (unsigned long long)T, (unsigned long long)n_timesteps,
+                                           (unsigned long long)step_begin, (unsigned long long)step_end, (unsigned long long)p->nsub};
+    for (int h = 0; h < p->nsub; ++h) key.push_back((unsigned long long)p->sub[h]);
+    for (auto &g : p->graphs)
+        if (g.key == key) {
+            g.used = ++p->graph_clock;
+            HIPCHK(hipGraphLaunch(g.exec, st));
+            return GTTS_OK;
+        }
+    HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+    rc = enqueue_reverse_diffusion(p, packed, z, mask, mu, spk, noise, out, workspace, workspace_bytes, B, T, n_timesteps,
+                                   step_begin, step_end, st);
+    hipGraph_t graph = nullptr;
+    const hipError_t ec = hipStreamEndCapture(st, &graph);
+    if (rc != GTTS_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (ec != hipSuccess || !graph) return fail(GTTS_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ec));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (ei != hipSuccess) { (void)hipGraphDestroy(graph); return fail(GTTS_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ei)); }
+    if (p->graphs.size() >= 8) {      // bounded cache: drop the least recently used graph
+        size_t lru = 0;
+        for (size_t i = 1; i < p->graphs.size(); ++i) if (p->graphs[i].used < p->graphs[lru].used) lru = i;
+        (void)hipGraphExecDestroy(p->graphs[lru].exec); (void)hipGraphDestroy(p->graphs[lru].graph);
+        p->graphs.erase(p->graphs.begin() + lru);
+    }
+    p->graphs.push_back({key, graph, exec, ++p->graph_clock});
+    HIPCHK(hipGraphLaunch(exec, st));
+    return GTTS_OK;
 }
 
 
@@ -1248,8 +1316,16 @@ extern "C" int gtts_expand_alignment(const float *duration, const float *x_mask,
 }
 
 
+extern "C" int gtts_log_prior(const float *mu_x, const float *y, float *log_prior, int B, int F, int t_x, int T,
+                              gtts_stream_t stream) {
+    if (!mu_x || !y || !log_prior) return fail(GTTS_E_NULL, "gtts_log_prior: null argument");
+    if (B <= 0 || F <= 0 || t_x <= 0 || T <= 0) return fail(GTTS_E_SHAPE, "gtts_log_prior: bad shape B=%d F=%d t_x=%d T=%d", B, F, t_x, T);
+    HIPCHK(launch_log_prior(mu_x, y, log_prior, B, F, t_x, T, (hipStream_t)stream));
+    return GTTS_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ measurement
-static std::string conv_kernel_name(int mode, int cin, int cout, int pro, int epi, int nsplit) {
+static std::string conv_kernel_name(int mode, int cin, int cout, int pro, int epi, int nsplit, bool abf = false) {
     const bool wide = cout > 64;
     const int kch = conv_geom(mode, cin, cout).kch;
     int wm, wn, mf;
@@ -1257,8 +1333,8 @@ static std::string conv_kernel_name(int mode, int cin, int cout, int pro, int ep
     else if (wide) { wm = 2; wn = 2; mf = 2; }
     else { wm = 1; wn = 4; mf = 2; }
     char buf[112];
-    snprintf(buf, sizeof buf, "gtts::conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d>", mode, wm, wn, mf, kch, pro, epi, nsplit,
-             cin % 16 == 0 ? 1 : 0);
+    snprintf(buf, sizeof buf, "gtts::conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d, %s>", mode, wm, wn, mf, kch, pro, epi, nsplit,
+             cin % 16 == 0 ? 1 : 0, abf ? "__bf16" : "float");
     return buf;
 }
 
@@ -1272,14 +1348,16 @@ extern "C" int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, con
     const int n = (int)plan->ops.size();
     if (i < 0 || i >= n + XOP_COUNT) return fail(GTTS_E_SHAPE, "op index out of range");
     const double F = plan->cfg.n_feats;
+    const double ab = plan->cfg.precision == GTTS_PREC_BF16_STORE ? 2.0 : 4.0;      // bytes per stored activation
+    const bool abf = plan->cfg.precision == GTTS_PREC_BF16_STORE;
     double fl = 0, by = 0;
     if (i >= n) {
         const double FT = F * T * B;
         switch (i - n) {
-            case XOP_PREP: s_label = "prep_input"; s_kernel = "gtts::prep_input_kernel"; by = 4.0 * FT * 2 * plan->cin0; break;
+            case XOP_PREP: s_label = "prep_input"; s_kernel = abf ? "gtts::prep_input_kernel<__bf16>" : "gtts::prep_input_kernel<float>"; by = (4.0 + ab) * FT * plan->cin0; break;
             case XOP_TIME: s_label = "time_mlp"; s_kernel = "gtts::time_mlp_kernel"; break;
-            case XOP_FINAL: s_label = "final_conv+euler"; s_kernel = "gtts::final_euler_kernel";
-                fl = 2.0 * plan->cfg.dim * FT; by = 4.0 * FT * (plan->cfg.dim + 4); break;
+            case XOP_FINAL: s_label = "final_conv+euler"; s_kernel = abf ? "gtts::final_euler_kernel<__bf16>" : "gtts::final_euler_kernel<float>";
+                fl = 2.0 * plan->cfg.dim * FT; by = FT * (ab * plan->cfg.dim + 16.0); break;
             case XOP_MULMASK: s_label = "xt=z*mask"; s_kernel = "gtts::mul_mask_kernel"; by = 8.0 * FT; break;
             case XOP_SPK: s_label = "spk_mlp"; s_kernel = "gtts::spk_mlp_kernel"; break;
         }
@@ -1292,16 +1370,22 @@ extern "C" int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, con
                 const double cin = o.c0 + o.c1;
                 const double taps = o.mode == CONV_P1 ? 1 : (o.mode == CONV_UP ? 4 : 9);
                 fl = 2.0 * B * o.cout * cin * taps * Ho * Wo;
-                by = 4.0 * B * (cin * Hi * Wi + o.cout * Ho * Wo);
-                if (o.epi == EPI_TAIL || o.epi == EPI_ATTN) by += 4.0 * B * o.cout * Ho * Wo;
-                s_kernel = conv_kernel_name(o.mode, o.c0 + o.c1, o.cout, o.pro, o.epi, plan->cfg.precision == GTTS_PREC_BF16 ? 1 : 2);
+                by = ab * B * (cin * Hi * Wi + o.cout * Ho * Wo);
+                if (o.epi == EPI_TAIL || o.epi == EPI_ATTN) by += ab * B * o.cout * Ho * Wo;
+                s_kernel = conv_kernel_name(o.mode, o.c0 + o.c1, o.cout, o.pro, o.epi, plan->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1,
+                                            plan->cfg.precision == GTTS_PREC_BF16_STORE);
                 break;
             }
             case OP_GNFIN: s_kernel = "gtts::gn_finalize_kernel"; break;
-            case OP_TAILID: s_kernel = "gtts::tail_identity_kernel"; by = 4.0 * B * o.C * Hi * Wi * 3; break;
-            case OP_ACTX: s_kernel = plan->cfg.precision == GTTS_PREC_BF16 ? (o.C % 32 == 0 ? "gtts::attn_ctx_kernel<1, 1>" : "gtts::attn_ctx_kernel<1, 0>")
-                                                                           : (o.C % 32 == 0 ? "gtts::attn_ctx_kernel<2, 1>" : "gtts::attn_ctx_kernel<2, 0>"); fl = 2.0 * B * Hi * Wi * (256.0 * o.C + 128.0 * 32);
-                by = 4.0 * B * o.C * Hi * Wi; break;
+            case OP_TAILID: s_kernel = abf ? "gtts::tail_identity_kernel<4, __bf16>" : "gtts::tail_identity_kernel<4, float>"; by = ab * B * o.C * Hi * Wi * 3; break;
+            case OP_ACTX: {
+                char nb[96];
+                snprintf(nb, sizeof nb, "gtts::attn_ctx_kernel<%d, %d, %s>", plan->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1, o.C % 32 == 0 ? 1 : 0,
+                         abf ? "__bf16" : "float");
+                s_kernel = nb;
+                fl = 2.0 * B * Hi * Wi * (256.0 * o.C + 128.0 * 32);
+                by = ab * B * o.C * Hi * Wi; break;
+            }
             case OP_AMERGE: s_kernel = "gtts::attn_merge_kernel"; break;
             case OP_INSTATS: s_kernel = "gtts::instnorm_stats_kernel"; by = 4.0 * B * o.C * Hi * Wi; break;
             case OP_REFPOOL: s_kernel = "gtts::ref_pool_kernel"; by = 8.0 * B * o.C * Hi * Wi; break;

@@ -190,9 +190,10 @@ class GradLogPEstimator2d(BaseModule):
 
     # ---- HIP plumbing -------------------------------------------------------------------------------
     def set_precision(self, precision):
-        """'bf16x3' (default, fp32-grade) or 'bf16' (BASELINE config 3)."""
+        """'bf16x3' (default, fp32-grade), 'bf16' (single bf16 MFMA, fp32 activations) or 'bf16_store' (BASELINE
+        config 3 as written: bf16 MFMA and bf16 activation storage)."""
         be = backend()
-        self._precision = {"bf16x3": be.PREC_BF16X3, "bf16": be.PREC_BF16}[precision]
+        self._precision = {"bf16x3": be.PREC_BF16X3, "bf16": be.PREC_BF16, "bf16_store": be.PREC_BF16_STORE}[precision]
         self._hip_plan = None
         self.invalidate_packed()
 

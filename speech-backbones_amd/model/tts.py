@@ -70,47 +70,57 @@ class GradTTS(BaseModule):
         # reference quirk kept (tts.py:99): the slice below indexes the t_x axis of attn [B,1,t_x,T]
         return encoder_outputs, decoder_outputs, attn[:, :, :y_max_length]
 
+    @staticmethod
+    def _mas_scores(mu_x, y):
+        """log N(y_j; mu_x_i, I) for every (token, frame) pair -> [B, t_x, T]   (tts.py:130-139).
+
+        HIP tensors: one launch of gtts_log_prior, handed to MAS without leaving the device.  Host tensors (CPU-side
+        training / tests): the same quantity from three reductions."""
+        if mu_x.is_cuda:
+            return backend().log_prior(mu_x, y)
+        n_feats = mu_x.shape[1]
+        energy_y = y.pow(2).sum(1)                                   # [B, T]
+        energy_mu = mu_x.pow(2).sum(1)                               # [B, t_x]
+        cross = torch.einsum("bfi,bfj->bij", mu_x, y)                # [B, t_x, T]
+        return cross - 0.5 * energy_y.unsqueeze(1) - 0.5 * energy_mu.unsqueeze(2) - 0.5 * math.log(2 * math.pi) * n_feats
+
     def compute_loss(self, x, x_lengths, y, y_lengths, spk=None, out_size=None):
-        """(duration loss, prior loss, diffusion loss)   (tts.py:101-181)."""
+        """(duration loss, prior loss, diffusion loss)   (tts.py:101-181).
+
+        x [B,t_x] token ids, y [B,F,T] target mels; out_size: frames of the random training crop (None = no crop)."""
         x, x_lengths, y, y_lengths = self.relocate_input([x, x_lengths, y, y_lengths])
         if self.n_spks > 1:
             spk = self.spk_emb(spk)
         mu_x, logw, x_mask = self.encoder(x, x_lengths, spk)
-        y_max_length = y.shape[-1]
-        y_mask = sequence_mask(y_lengths, y_max_length).unsqueeze(1).to(x_mask)
-        attn_mask = x_mask.unsqueeze(-1) * y_mask.unsqueeze(2)
+        frames = y.shape[-1]
+        y_mask = sequence_mask(y_lengths, frames).unsqueeze(1).to(x_mask)
+        pair_mask = x_mask.unsqueeze(-1) * y_mask.unsqueeze(2)       # [B, 1, t_x, T]
 
-        # MAS over the Gaussian log-likelihood of every (token, frame) pair (tts.py:130-139)
+        # hard alignment: most likely monotonic path through the (token, frame) log-likelihood matrix
         with torch.no_grad():
-            const = -0.5 * math.log(2 * math.pi) * self.n_feats
-            factor = -0.5 * torch.ones(mu_x.shape, dtype=mu_x.dtype, device=mu_x.device)
-            y_square = torch.matmul(factor.transpose(1, 2), y ** 2)
-            y_mu_double = torch.matmul(2.0 * (factor * mu_x).transpose(1, 2), y)
-            mu_square = torch.sum(factor * (mu_x ** 2), 1).unsqueeze(-1)
-            log_prior = y_square - y_mu_double + mu_square + const
-            attn = monotonic_align.maximum_path(log_prior, attn_mask.squeeze(1)).detach()
+            attn = monotonic_align.maximum_path(self._mas_scores(mu_x, y), pair_mask.squeeze(1)).detach()
 
-        logw_ = torch.log(1e-8 + torch.sum(attn.unsqueeze(1), -1)) * x_mask
-        dur_loss = duration_loss(logw, logw_, x_lengths)
+        # duration predictor target = log of the frames MAS gave each token (tts.py:141-143)
+        frames_per_token = attn.sum(-1).unsqueeze(1)
+        dur_loss = duration_loss(logw, torch.log(1e-8 + frames_per_token) * x_mask, x_lengths)
 
-        if out_size is not None:          # random crop to out_size frames per item (tts.py:146-168)
-            max_offset = (y_lengths - out_size).clamp(0)
-            starts = [random.choice(range(0, int(e))) if int(e) > 0 else 0 for e in max_offset.cpu().numpy()]
-            out_offset = torch.LongTensor(starts).to(y_lengths)
-            attn_cut = torch.zeros(attn.shape[0], attn.shape[1], out_size, dtype=attn.dtype, device=attn.device)
-            y_cut = torch.zeros(y.shape[0], self.n_feats, out_size, dtype=y.dtype, device=y.device)
-            y_cut_lengths = []
-            for i, (y_, off) in enumerate(zip(y, out_offset)):
-                n = out_size + (y_lengths[i] - out_size).clamp(None, 0)
-                y_cut_lengths.append(n)
-                y_cut[i, :, :n] = y_[:, off:off + n]
-                attn_cut[i, :, :n] = attn[i, :, off:off + n]
-            y_cut_lengths = torch.LongTensor(y_cut_lengths)
-            attn, y = attn_cut, y_cut
-            y_mask = sequence_mask(y_cut_lengths).unsqueeze(1).to(y_mask)
+        if out_size is not None:
+            # random out_size-frame window per utterance (tts.py:146-168), taken with one gather instead of a loop;
+            # the window starts consume Python's `random` stream exactly like the reference's random.choice(range(n))
+            slack = (y_lengths - out_size).clamp(min=0).tolist()
+            starts = torch.tensor([random.randrange(int(n)) if int(n) > 0 else 0 for n in slack], dtype=torch.long,
+                                  device=y.device)
+            kept = torch.clamp(y_lengths, max=out_size)
+            col = torch.arange(out_size, device=y.device)
+            src = (starts.unsqueeze(1) + col.unsqueeze(0)).clamp(max=frames - 1)        # [B, out_size]
+            live = (col.unsqueeze(0) < kept.unsqueeze(1)).unsqueeze(1)                   # [B, 1, out_size]
+            y = torch.gather(y, 2, src.unsqueeze(1).expand(-1, y.shape[1], -1)) * live.to(y.dtype)
+            attn = torch.gather(attn, 2, src.unsqueeze(1).expand(-1, attn.shape[1], -1)) * live.to(attn.dtype)
+            y_mask = sequence_mask(kept).unsqueeze(1).to(y_mask)
 
-        mu_y = torch.matmul(attn.squeeze(1).transpose(1, 2), mu_x.transpose(1, 2)).transpose(1, 2)
+        # aligned prior mean, diffusion loss on the decoder, Gaussian prior loss of the encoder (tts.py:171-181)
+        mu_y = torch.matmul(attn.transpose(1, 2), mu_x.transpose(1, 2)).transpose(1, 2)
         diff_loss, _ = self.decoder.compute_loss(y, y_mask, mu_y, spk)
-        prior_loss = torch.sum(0.5 * ((y - mu_y) ** 2 + math.log(2 * math.pi)) * y_mask)
-        prior_loss = prior_loss / (torch.sum(y_mask) * self.n_feats)
+        nll = 0.5 * ((y - mu_y) ** 2 + math.log(2 * math.pi)) * y_mask
+        prior_loss = nll.sum() / (y_mask.sum() * self.n_feats)
         return dur_loss, prior_loss, diff_loss

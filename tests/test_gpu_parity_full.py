@@ -22,6 +22,7 @@ from oracle import gradtts_oracle as O
 pytestmark = pytest.mark.gpu
 REL = 1e-4          # bf16x3 contractions, fp32 accumulate (measured ~2e-5 per call)
 REL_BF16 = 2.5e-2   # plain-bf16 contractions (config 3), single estimator call (measured ~8e-3)
+REL_BF16_STORE = 4e-2   # bf16 contractions AND bf16 activation storage (config 3 as written)
 
 
 @pytest.fixture(scope="module")
@@ -58,7 +59,7 @@ def test_reverse_diffusion_n50_t1024_vs_oracle(S, dev):
 
 
 def test_reverse_diffusion_n50_t1024_mel_scale_abs(S, dev):
-    """Same N and T on the mel-scale fixture (sample stays |x| < 15): the north-star's literal 1e-3 max-abs."""
+    """Same N and T on the mel-scale fixture (sample stays |x| < 20): the north-star's literal 1e-3 max-abs."""
     sd = dict(O.make_estimator_state(seed=0))
     sd["final_conv.weight"] = sd["final_conv.weight"] * 0.1
     sd["final_conv.bias"] = sd["final_conv.bias"] * 0.1
@@ -68,7 +69,7 @@ def test_reverse_diffusion_n50_t1024_mel_scale_abs(S, dev):
     ref = O.reverse_diffusion(sd, inp["z"], inp["mask"], inp["mu"], 50)
     out = plan.reverse_diffusion(blob, inp["z"].to(dev), inp["mask"].to(dev), inp["mu"].to(dev), 50).cpu()
     print("mel-scale N=50: max|ref| %.4g  max|err| %.3e" % (float(ref.abs().max()), float((out - ref).abs().max())))
-    assert 1.0 < float(ref.abs().max()) < 15
+    assert 1.0 < float(ref.abs().max()) < 20
     assert float((out - ref).abs().max()) <= 1e-3
 
 
@@ -294,7 +295,7 @@ def test_config3_bf16_multispeaker_teacher_forced_n100(S, dev):
     m, mu, spk = inp["mask"].to(dev), inp["mu"].to(dev), inp["spk"].to(dev)
     h = 1.0 / 100
     worst = {}
-    for prec, every in (("bf16", 1), ("bf16x3", 10)):
+    for prec, every in (("bf16", 1), ("bf16_store", 1), ("bf16x3", 10)):
         dec.estimator.set_precision(prec)
         w = 0.0
         for i in range(0, 100, every):
@@ -304,9 +305,11 @@ def test_config3_bf16_multispeaker_teacher_forced_n100(S, dev):
                 got = dec.estimator(xt.to(dev), m, mu, t.to(dev), spk).cpu()
             w = max(w, relerr(got, est))
         worst[prec] = w
-    print("teacher-forced N=100, 247 speakers: worst rel err bf16 %.2e, bf16x3 %.2e" % (worst["bf16"], worst["bf16x3"]))
+    print("teacher-forced N=100, 247 speakers: worst rel err bf16 %.2e, bf16_store %.2e, bf16x3 %.2e" %
+          (worst["bf16"], worst["bf16_store"], worst["bf16x3"]))
     assert worst["bf16x3"] <= REL
     assert worst["bf16x3"] < worst["bf16"] <= REL_BF16
+    assert worst["bf16_store"] <= REL_BF16_STORE
 
 
 def test_config3_bf16_gradtts_forward_with_spk(S, dev):
@@ -318,17 +321,18 @@ def test_config3_bf16_gradtts_forward_with_spk(S, dev):
     sd["final_conv.weight"] = sd["final_conv.weight"] * 0.1
     sd["final_conv.bias"] = sd["final_conv.bias"] * 0.1
     model.decoder.estimator.load_state_dict(sd, strict=True)
-    model.decoder.estimator.set_precision("bf16")
     g = torch.Generator().manual_seed(8)
     x = torch.randint(0, 149, (2, 21), generator=g)
     xl = torch.tensor([21, 14])
     spk = torch.tensor([17, 200])
-    torch.manual_seed(3)
-    dec_out = model(x.to(dev), xl.to(dev), n_timesteps=10, temperature=1.5, spk=spk.to(dev))[1]
     ref, _ = _tts_reference(model, sd, x, xl, spk, 10, 1.0, 3, dev)
-    e = relerr(dec_out.cpu(), ref)
-    print("GradTTS(247 spk, bf16) N=10 free-running rel err %.2e" % e)
-    assert e <= REL_BF16
+    for prec, tol in (("bf16", REL_BF16), ("bf16_store", REL_BF16_STORE)):
+        model.decoder.estimator.set_precision(prec)
+        torch.manual_seed(3)
+        dec_out = model(x.to(dev), xl.to(dev), n_timesteps=10, temperature=1.5, spk=spk.to(dev))[1]
+        e = relerr(dec_out.cpu(), ref)
+        print("GradTTS(247 spk, %s) N=10 free-running rel err %.2e" % (prec, e))
+        assert e <= tol
 
 
 # ------------------------------------------------------------------------------------------------ config 4
@@ -347,3 +351,79 @@ def test_vc_dim256_t1024_single_call(S, dev):
     e = relerr(out, ref)
     print("DiffVC dim256 T=1024: rel err %.2e" % e)
     assert e <= REL
+
+
+# ------------------------------------------------------------------------------------------------ hipGraph replay
+def test_graph_replay_is_bit_identical_to_eager(S, dev):
+    """gtts_plan_set_graph: the captured-and-replayed sampler call (B=1, the inference.py regime) returns exactly the
+    eager result, on the capture call, on replays, and after the inputs changed in place (same addresses)."""
+    sd = O.make_estimator_state(seed=0)
+    eager = S.Plan()
+    blob = eager.pack(sd, dev)
+    gp = S.Plan()
+    gp.set_graph(True)
+    for seed in (1, 2, 3):
+        inp = O.make_inputs(1, 64, seed=seed, ragged=False)
+        z, m, mu = inp["z"].to(dev), inp["mask"].to(dev), inp["mu"].to(dev)
+        want = eager.reverse_diffusion(blob, z, m, mu, 5)
+        got = gp.reverse_diffusion(blob, z, m, mu, 5)
+        assert torch.equal(got, want), seed
+    inp = O.make_inputs(3, 32, seed=9)                     # another shape: a second graph, sub-batch streams inside it
+    z, m, mu = inp["z"].to(dev), inp["mask"].to(dev), inp["mu"].to(dev)
+    for _ in range(2):
+        assert torch.equal(gp.reverse_diffusion(blob, z, m, mu, 3), eager.reverse_diffusion(blob, z, m, mu, 3))
+    ref = O.reverse_diffusion(sd, inp["z"], inp["mask"], inp["mu"], 3)
+    assert relerr(gp.reverse_diffusion(blob, z, m, mu, 3).cpu(), ref) <= REL
+    gp.set_graph(False)
+    assert torch.equal(gp.reverse_diffusion(blob, z, m, mu, 3), eager.reverse_diffusion(blob, z, m, mu, 3))
+
+
+# ------------------------------------------------------------------------------------------------ f2: MAS score matrix
+def test_log_prior_kernel_and_mas_on_device(S, dev):
+    """gtts_log_prior (tts.py:130-139) at training shapes: the matrix itself <= 1e-5 * max|ref| against the reference's
+    three-matmul expression, and -- bit-exactness being required of the PATH given identical scores -- the GPU MAS on the
+    GPU scores equals the plain-C oracle MAS fed the same GPU scores."""
+    import math
+    from oracle import mas as MAS
+    g = torch.Generator().manual_seed(12)
+    B, Fm, tx, T = 4, 80, 57, 236
+    mu_x = torch.randn(B, Fm, tx, generator=g)
+    y = torch.randn(B, Fm, T, generator=g) * 1.3
+    factor = -0.5 * torch.ones_like(mu_x)
+    ref = (torch.matmul(factor.transpose(1, 2), y ** 2) - torch.matmul(2.0 * (factor * mu_x).transpose(1, 2), y)
+           + torch.sum(factor * mu_x ** 2, 1).unsqueeze(-1) - 0.5 * math.log(2 * math.pi) * Fm)
+    got = S._lib.log_prior(mu_x.to(dev), y.to(dev))
+    assert got.shape == (B, tx, T)
+    assert relerr(got.cpu(), ref) <= 1e-5
+    xl = torch.tensor([57, 40, 13, 57])
+    yl = torch.tensor([236, 200, 90, 150])
+    mask = (O.sequence_mask(xl, tx).unsqueeze(-1) * O.sequence_mask(yl, T).unsqueeze(1)).float()
+    path = S.mas_maximum_path(got, mask.to(dev)).cpu()
+    assert torch.equal(path, MAS.maximum_path_port(got.cpu(), mask))
+
+
+def test_gradtts_compute_loss_on_gpu(S, dev):
+    """GradTTS.compute_loss on the GPU (encoder -> gtts_log_prior -> gtts_mas_maximum_path -> losses) against the same
+    module on the CPU: duration and prior losses are deterministic given the weights and must agree; the diffusion loss
+    draws device noise and is only checked for finiteness and a gradient on every decoder parameter."""
+    import copy
+    M = importlib.import_module("speech-backbones_amd.model")
+    torch.manual_seed(0)
+    model = M.GradTTS(149, 1, 64, 192, 768, 256, 2, 6, 3, 0.1, 4, 80, 64, 0.05, 20.0, 1000).train()
+    for mod in model.modules():                   # dropout off: CPU and GPU draw different masks
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    cpu = copy.deepcopy(model)
+    model = model.to(dev)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(0, 149, (3, 41), generator=g)
+    xl = torch.tensor([41, 30, 12])
+    y = torch.randn(3, 80, 120, generator=g)
+    yl = torch.tensor([120, 96, 60])
+    a = model.compute_loss(x.to(dev), xl.to(dev), y.to(dev), yl.to(dev))
+    b = cpu.compute_loss(x, xl, y, yl)
+    assert abs(float(a[0]) - float(b[0])) <= 1e-4 * max(1.0, abs(float(b[0])))
+    assert abs(float(a[1]) - float(b[1])) <= 1e-4 * max(1.0, abs(float(b[1])))
+    assert torch.isfinite(a[2])
+    sum(a).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.decoder.parameters())
