@@ -184,6 +184,34 @@ int gtts_expand_alignment(const float *duration, const float *x_mask, const int 
  * Evaluated as -0.5 sum_f (y - mu)^2 - 0.5 F log(2 pi): equal to the reference's three-matmul form up to fp32 rounding. */
 int gtts_log_prior(const float *mu_x, const float *y, float *log_prior, int B, int F, int t_x, int T, gtts_stream_t stream);
 
+/* ---- HiFi-GAN generator: mel -> waveform, the step after the sampling path (Grad-TTS/inference.py:81;
+ * Grad-TTS/hifi-gan/models.py:77-128, configuration Grad-TTS/checkpts/hifigan-config.json) ------------------------------ */
+typedef struct gtts_voc_cfg {
+    int n_mels;                       /* 80                                                            */
+    int upsample_initial_channel;     /* 512                                                           */
+    int n_ups;                        /* len(upsample_rates), <= 8                                     */
+    int upsample_rates[8];            /* 8,8,2,2      (powers of two)                                  */
+    int upsample_kernel_sizes[8];     /* 16,16,4,4    (= 2 * rate)                                     */
+    int n_kernels;                    /* len(resblock_kernel_sizes), <= 8                              */
+    int resblock_kernel_sizes[8];     /* 3,7,11       (odd, <= 11)                                     */
+    int resblock_dilations[8][3];     /* 1,3,5 each   (ResBlock2 uses the first two)                   */
+    int resblock_type;                /* 1: ResBlock1 (models.py:13-50), 2: ResBlock2 (:53-74)         */
+} gtts_voc_cfg;
+typedef struct gtts_voc gtts_voc;     /* host-side metadata only */
+int gtts_voc_create(const gtts_voc_cfg *cfg, gtts_voc **out);
+void gtts_voc_destroy(gtts_voc *voc);
+/* parameter i of the layout the packer expects: `<module path>.weight` / `.bias` with weight normalisation already
+ * folded (Generator.remove_weight_norm, models.py:122-128); Conv1d weights [cout][cin][k], ConvTranspose1d [cin][cout][k] */
+int gtts_voc_num_params(const gtts_voc *voc);
+int gtts_voc_param_info(const gtts_voc *voc, int i, const char **name, int *rank, int dims[4]);
+size_t gtts_voc_packed_bytes(const gtts_voc *voc);
+int gtts_voc_pack(const gtts_voc *voc, const void *const *param_ptrs, int n_params, void *packed, gtts_stream_t stream);
+size_t gtts_voc_workspace_bytes(const gtts_voc *voc, int B, int T);
+int gtts_voc_hop(const gtts_voc *voc);          /* output samples per mel frame (product of the rates: 256) */
+/* Generator.forward: mel [B, n_mels, T] fp32 -> wav [B, 1, T * hop] fp32 in (-1, 1). */
+int gtts_voc_forward(const gtts_voc *voc, const void *packed, const float *mel, float *wav, void *workspace,
+                     size_t workspace_bytes, int B, int T, gtts_stream_t stream);
+
 /* ---- debugging / tests: named intermediates of the last estimator call (keep_intermediates plans) ----- */
 int gtts_plan_num_tensors(const gtts_plan *plan);
 /* offset is in bytes into the workspace for the given (B,T); dims = {B,C,H,W}. */

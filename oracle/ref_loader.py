@@ -76,3 +76,36 @@ def load_diffvc():
             sys.modules.pop(name, None)
     return types.SimpleNamespace(diffusion=mods["model.diffusion"], modules=mods["model.modules"],
                                  vc=mods.get("model.vc"))
+
+
+def load_hifigan():
+    """Return the reference HiFi-GAN `models` / `env` modules (Grad-TTS/hifi-gan/; top-level names `models`, `env`,
+    `xutils` exactly as inference.py:19-20 imports them after sys.path.append('./hifi-gan/'))."""
+    path = os.path.join(REF_ROOT, "Grad-TTS", "hifi-gan")
+    if not os.path.isdir(path):
+        raise RuntimeError("/root/reference is not mounted")
+    names = ("models", "env", "xutils")
+    saved = {k: sys.modules.pop(k) for k in names if k in sys.modules}
+    stubs = {}
+    try:
+        import matplotlib  # noqa: F401  (xutils.py:5-8 imports it for plotting helpers)
+    except Exception:
+        for name in ("matplotlib", "matplotlib.pylab"):
+            stubs[name] = types.ModuleType(name)
+            sys.modules[name] = stubs[name]
+        stubs["matplotlib"].use = lambda *a, **k: None
+        stubs["matplotlib"].pylab = stubs["matplotlib.pylab"]
+    sys.path.insert(0, path)
+    try:
+        import models  # noqa: F401
+        import env  # noqa: F401
+        mods = {k: sys.modules[k] for k in names}
+    finally:
+        sys.path.remove(path)
+        for k in names:
+            sys.modules.pop(k, None)
+        sys.modules.update(saved)
+        for name in stubs:
+            sys.modules.pop(name, None)
+    return types.SimpleNamespace(models=mods["models"], env=mods["env"], Generator=mods["models"].Generator,
+                                 AttrDict=mods["env"].AttrDict)

@@ -29,6 +29,13 @@ class UnetCfg(ctypes.Structure):
                 ("vc_beta_max", ctypes.c_double)]
 
 
+class VocCfg(ctypes.Structure):
+    _fields_ = [("n_mels", ctypes.c_int), ("upsample_initial_channel", ctypes.c_int), ("n_ups", ctypes.c_int),
+                ("upsample_rates", ctypes.c_int * 8), ("upsample_kernel_sizes", ctypes.c_int * 8),
+                ("n_kernels", ctypes.c_int), ("resblock_kernel_sizes", ctypes.c_int * 8),
+                ("resblock_dilations", (ctypes.c_int * 3) * 8), ("resblock_type", ctypes.c_int)]
+
+
 def lib():
     """Load the HIP library (once).  Fails loudly when it has not been built."""
     global _lib
@@ -67,6 +74,18 @@ def lib():
         L.gtts_mas_maximum_path.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, vp]
         L.gtts_expand_alignment.argtypes = [vp, vp, vp, vp, vp, f, vp, vp, vp, i, i, i, i, vp]
         L.gtts_log_prior.argtypes = [vp, vp, vp, i, i, i, i, vp]
+        L.gtts_voc_create.argtypes = [ctypes.POINTER(VocCfg), ctypes.POINTER(vp)]
+        L.gtts_voc_destroy.argtypes = [vp]
+        L.gtts_voc_destroy.restype = None
+        L.gtts_voc_num_params.argtypes = [vp]
+        L.gtts_voc_param_info.argtypes = [vp, i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(i), ctypes.POINTER(i * 4)]
+        L.gtts_voc_packed_bytes.argtypes = [vp]
+        L.gtts_voc_packed_bytes.restype = sz
+        L.gtts_voc_pack.argtypes = [vp, ctypes.POINTER(vp), i, vp, vp]
+        L.gtts_voc_workspace_bytes.argtypes = [vp, i, i]
+        L.gtts_voc_workspace_bytes.restype = sz
+        L.gtts_voc_hop.argtypes = [vp]
+        L.gtts_voc_forward.argtypes = [vp, vp, vp, vp, vp, sz, i, i, vp]
         L.gtts_plan_num_tensors.argtypes = [vp]
         L.gtts_plan_tensor_info.argtypes = [vp, i, i, i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz),
                                             ctypes.POINTER(i * 4)]
@@ -136,6 +155,7 @@ class Plan:
         self._nstreams = 0 if int(streams) < 2 else min(int(streams), 4)
         self._side = None           # (device, [torch.cuda.Stream])
         self._graph = False
+        self._gstream = None
         self._stage = {}            # graph mode: persistent argument buffers (stable addresses -> graph cache hits)
 
     # a Plan is host metadata: copies / pickles rebuild it from its constructor arguments (EMA deep copies,
@@ -152,6 +172,7 @@ class Plan:
         _check(lib().gtts_plan_set_graph(self._h, 1 if on else 0), "gtts_plan_set_graph")
         self._graph = bool(on)
         self._stage = {}
+        self._gstream = None        # capture / replay stream (stream capture is not allowed on the default stream)
 
     def _use_streams(self, device):
         """Register this plan's side streams for `device` (created once; they belong to this object)."""
@@ -273,10 +294,21 @@ class Plan:
         else:
             out = torch.empty_like(z)
         with torch.cuda.device(z.device):
+            if self._graph:
+                cur = torch.cuda.current_stream()
+                if self._gstream is None or self._gstream.device != z.device:
+                    self._gstream = torch.cuda.Stream(device=z.device)
+                self._gstream.wait_stream(cur)
+                with torch.cuda.stream(self._gstream):
+                    _check(lib().gtts_reverse_diffusion(self._h, _ptr(blob), _ptr(z), _ptr(mask), _ptr(mu), _ptr(spk),
+                                                        _ptr(noise), _ptr(out), _ptr(ws), ws.numel(), B, T, int(n_timesteps),
+                                                        0, int(n_timesteps), _stream()), "gtts_reverse_diffusion")
+                cur.wait_stream(self._gstream)
+                return out.clone()
             _check(lib().gtts_reverse_diffusion(self._h, _ptr(blob), _ptr(z), _ptr(mask), _ptr(mu), _ptr(spk),
                                                 _ptr(noise), _ptr(out), _ptr(ws), ws.numel(), B, T, int(n_timesteps),
                                                 0, int(n_timesteps), _stream()), "gtts_reverse_diffusion")
-        return out.clone() if self._graph else out
+        return out
 
     # ---- DiffVC (arch=1)
     def vc_workspace(self, B, T, Tr, device):
@@ -394,6 +426,108 @@ class Plan:
             view = ws[off.value: off.value + 4 * n].view(torch.float32).view(*dims)
             out[name.value.decode()] = view
         return out
+
+
+class Vocoder:
+    """HiFi-GAN generator on the HIP kernels (csrc/voc.hip): Generator(h).forward of Grad-TTS/hifi-gan/models.py:77-120."""
+
+    def __init__(self, upsample_rates=(8, 8, 2, 2), upsample_kernel_sizes=(16, 16, 4, 4), upsample_initial_channel=512,
+                 resblock_kernel_sizes=(3, 7, 11), resblock_dilation_sizes=((1, 3, 5), (1, 3, 5), (1, 3, 5)), resblock="1",
+                 n_mels=80):
+        self._kw = dict(upsample_rates=tuple(upsample_rates), upsample_kernel_sizes=tuple(upsample_kernel_sizes),
+                        upsample_initial_channel=int(upsample_initial_channel),
+                        resblock_kernel_sizes=tuple(resblock_kernel_sizes),
+                        resblock_dilation_sizes=tuple(tuple(d) for d in resblock_dilation_sizes), resblock=str(resblock),
+                        n_mels=int(n_mels))
+        cfg = VocCfg()
+        cfg.n_mels = int(n_mels)
+        cfg.upsample_initial_channel = int(upsample_initial_channel)
+        cfg.n_ups = len(upsample_rates)
+        cfg.n_kernels = len(resblock_kernel_sizes)
+        cfg.resblock_type = int(resblock)
+        if cfg.n_ups > 8 or cfg.n_kernels > 8:
+            raise RuntimeError("at most 8 upsamplers / ResBlock kernels")
+        for k, (u, ks) in enumerate(zip(upsample_rates, upsample_kernel_sizes)):
+            cfg.upsample_rates[k] = int(u)
+            cfg.upsample_kernel_sizes[k] = int(ks)
+        for k, (ks, dil) in enumerate(zip(resblock_kernel_sizes, resblock_dilation_sizes)):
+            cfg.resblock_kernel_sizes[k] = int(ks)
+            for j in range(3):
+                cfg.resblock_dilations[k][j] = int(dil[j]) if j < len(dil) else 1
+        self.cfg = cfg
+        self._h = ctypes.c_void_p()
+        L = lib()
+        _check(L.gtts_voc_create(ctypes.byref(cfg), ctypes.byref(self._h)), "gtts_voc_create")
+        self.hop = int(L.gtts_voc_hop(self._h))
+        self._ws = {}
+
+    @classmethod
+    def from_config(cls, h):
+        """h: the AttrDict of hifigan-config.json (Grad-TTS/inference.py:57-59)."""
+        return cls(h["upsample_rates"], h["upsample_kernel_sizes"], h["upsample_initial_channel"],
+                   h["resblock_kernel_sizes"], h["resblock_dilation_sizes"], h["resblock"], h.get("num_mels", 80))
+
+    def __reduce__(self):
+        return (_rebuild_voc, (self._kw,))
+
+    def __deepcopy__(self, memo):
+        return Vocoder(**self._kw)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().gtts_voc_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def param_layout(self):
+        L = lib()
+        out = []
+        for k in range(L.gtts_voc_num_params(self._h)):
+            name, rank, dims = ctypes.c_char_p(), ctypes.c_int(), (ctypes.c_int * 4)()
+            _check(L.gtts_voc_param_info(self._h, k, ctypes.byref(name), ctypes.byref(rank), ctypes.byref(dims)),
+                   "gtts_voc_param_info")
+            out.append((name.value.decode(), tuple(dims[:rank.value])))
+        return out
+
+    def pack(self, state, device):
+        """state: name -> tensor with weight normalisation folded (`<module>.weight`, `<module>.bias`)."""
+        keep = []
+        for name, shape in self.param_layout():
+            if name not in state:
+                raise RuntimeError("state_dict is missing '%s' (call remove_weight_norm() or fold weight_g / weight_v)" % name)
+            t = state[name].detach().to(device=device, dtype=torch.float32).contiguous()
+            if tuple(t.shape) != shape:
+                raise RuntimeError("parameter %s has shape %s, expected %s" % (name, tuple(t.shape), shape))
+            keep.append(t)
+        arr = (ctypes.c_void_p * len(keep))(*[t.data_ptr() for t in keep])
+        blob = torch.empty(int(lib().gtts_voc_packed_bytes(self._h)), dtype=torch.uint8, device=device)
+        with torch.cuda.device(blob.device):
+            _check(lib().gtts_voc_pack(self._h, arr, len(keep), _ptr(blob), _stream()), "gtts_voc_pack")
+            torch.cuda.current_stream().synchronize()
+        return blob
+
+    def forward(self, blob, mel):
+        mel = _f32c(mel, "mel")
+        B, F, T = mel.shape
+        if F != self.cfg.n_mels:
+            raise RuntimeError("expected %d mel bins, got %d" % (self.cfg.n_mels, F))
+        key = (B, T, str(mel.device))
+        ws = self._ws.get(key)
+        if ws is None:
+            self._ws.clear()
+            ws = torch.empty(int(lib().gtts_voc_workspace_bytes(self._h, B, T)), dtype=torch.uint8, device=mel.device)
+            self._ws[key] = ws
+        wav = torch.empty((B, 1, T * self.hop), dtype=torch.float32, device=mel.device)
+        with torch.cuda.device(mel.device):
+            _check(lib().gtts_voc_forward(self._h, _ptr(blob), _ptr(mel), _ptr(wav), _ptr(ws), ws.numel(), B, T, _stream()),
+                   "gtts_voc_forward")
+        return wav
+
+
+def _rebuild_voc(kw):
+    return Vocoder(**kw)
 
 
 def _rebuild_plan(kw):

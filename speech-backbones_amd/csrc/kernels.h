@@ -4,6 +4,9 @@
 
 namespace gtts {
 
+// error text of the calling thread (plan.hip; returned by gtts_last_error)
+int set_error(int code, const char *msg);
+
 // ---- misc.hip
 struct TimeMlpDesc {
     int dim;                 // time embedding width (dec_dim)

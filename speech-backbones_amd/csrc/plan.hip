@@ -34,6 +34,9 @@ static int fail(int code, const char *fmt, ...) {
     g_err = buf;
     return code;
 }
+namespace gtts {
+int set_error(int code, const char *msg) { g_err = msg; return code; }     // for the other translation units
+}
 #define HIPCHK(expr)                                                                                        \
     do {                                                                                                    \
         hipError_t e_ = (expr);                                                                             \
@@ -1085,6 +1088,7 @@ extern "C" int gtts_reverse_diffusion(gtts_plan *plan, const void *packed, const
             HIPCHK(hipGraphLaunch(g.exec, st));
             return GTTS_OK;
         }
+    if (!st) return fail(GTTS_E_CONFIG, "hipGraph capture needs a non-default stream (got the null stream)");
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
     rc = enqueue_reverse_diffusion(p, packed, z, mask, mu, spk, noise, out, workspace, workspace_bytes, B, T, n_timesteps,
                                    step_begin, step_end, st);

@@ -1,0 +1,579 @@
+// voc.hip -- HiFi-GAN generator (mel -> waveform), the step right after the sampling path in Grad-TTS/inference.py:81
+// (SURVEY.md section 8f rank 3).  Reference: Grad-TTS/hifi-gan/models.py:77-128 (Generator), :13-75 (ResBlock1/2),
+// configuration Grad-TTS/checkpts/hifigan-config.json (V1: 512 channels, rates 8,8,2,2, kernels 3/7/11, dilations 1/3/5).
+//
+// Everything dense is ONE 1-D implicit-GEMM kernel on the bf16 MFMA pipe (split-bf16 hi/lo, 3 MFMAs per product, fp32
+// accumulate: fp32-grade like the decoder's convolutions):
+//     D[row m][position q] = sum_{tap, cin} W[m][cin, tap] * lrelu(X[cin][q + off(tap)])
+//   Conv1d(k, dilation d):        rows = cout, off(tap) = (tap - (k-1)/2) * d                       models.py:18-35,83
+//   ConvTranspose1d(k, stride s): rows = (cout, phase r) with r = output position mod s; every phase is a 2-tap
+//       convolution over the INPUT positions, the union over phases is a 3-tap convolution with per-row zero weights.
+//       The C/D fragment holds 4 consecutive rows per lane = consecutive output positions of one channel.  models.py:88-91
+// fused around it: LeakyReLU of the input on load (models.py:39,41,105,117), bias, the ResBlock residual `xt + x`
+// (:43), the sum over the three ResBlocks and the division by num_kernels (:110-114) in the reference's fp32 order.
+// Layout: [B][C][L] fp32, L fastest -> coalesced along time.  conv_post (32 -> 1 channel, tanh) is a VALU kernel.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/gradtts_abi.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace gtts {
+
+constexpr int C1_MAXTAP = 12;
+struct C1Args {
+    const float *x;          // [B][cin][Lin]
+    float *out;              // [B][cout][Lin * S]
+    const float *res;        // residual added to the result (same indexing as out) or nullptr
+    const float *accsrc;     // running sum over ResBlocks (accmode 1 / 2) or nullptr
+    const unsigned char *w;  // packed [chunk][stage][cot][split][tap][kg][MT][8] bf16
+    const float *bias;       // [cout]
+    int B, cin, cout, Lin, S;
+    int nchunk, nst;
+    int toff[C1_MAXTAP];     // input offset of padded tap t (zero-weight pad taps use offset 0)
+    int halo_lo, npx;        // -min(toff);  NT + halo_lo + max(toff)
+    float slope;             // LeakyReLU slope applied to the input on load (1 = identity)
+    int accmode;             // 0 none, 1 v = accsrc + v, 2 v = (accsrc + v) / div
+    float div;
+};
+
+template <int WM, int WN, int MF, int TPS, int AITER>
+__global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const C1Args a) {
+    constexpr int MT = WM * MF * 32, NT = WN * 64, NKG = 2;
+    constexpr int WBLK16 = 2 * TPS * NKG * MT;                 // 16-byte units per weight stage (hi + lo)
+    constexpr int WITER = (WBLK16 + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int NPX = a.npx;
+    u32x4 *s_ah = reinterpret_cast<u32x4 *>(smem);             // [NKG][NPX]
+    u32x4 *s_al = s_ah + NKG * NPX;
+    u32x4 *s_w = s_al + NKG * NPX;                             // [split][tap][kg][MT]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kgl = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int M = a.cout * a.S;
+    const int ncot = (M + MT - 1) / MT;
+    const int ntile = (a.Lin + NT - 1) / NT;
+    int wg = xcd_slot(blockIdx.x, gridDim.x);
+    const int cot = wg % ncot; wg /= ncot;
+    const int tile = wg % ntile;
+    const int b = wg / ntile;
+    const int q0 = tile * NT;
+    const float *xb = a.x + (size_t)b * a.cin * a.Lin;
+
+    // staging items: (8-channel group, halo position); geometry is chunk-invariant
+    int it_pos[AITER];
+    bool it_ok[AITER];
+#pragma unroll
+    for (int it = 0; it < AITER; ++it) {
+        const int idx = tid + it * 256;
+        const int p = idx % NPX;
+        const int t = q0 - a.halo_lo + p;
+        it_ok[it] = idx < NKG * NPX && t >= 0 && t < a.Lin;
+        it_pos[it] = it_ok[it] ? t : 0;
+    }
+    float araw[AITER][8];
+    auto load_act = [&](int chunk) {
+#pragma unroll
+        for (int it = 0; it < AITER; ++it) {
+            const int idx = tid + it * 256;
+            const int kg = min(idx / NPX, NKG - 1);
+            const int cb = chunk * 16 + kg * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = min(cb + i, a.cin - 1);
+                const float v = xb[(size_t)c * a.Lin + it_pos[it]];
+                araw[it][i] = (it_ok[it] && cb + i < a.cin) ? v : 0.f;
+            }
+        }
+    };
+    u32x4 wregs[WITER];
+    const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(a.w);
+    auto load_w = [&](int chunk, int stage) {
+        const size_t blk = ((size_t)chunk * a.nst + stage) * ncot + cot;
+#pragma unroll
+        for (int i = 0; i < WITER; ++i) {
+            const int u = tid + i * 256;
+            wregs[i] = wsrc[blk * WBLK16 + (u < WBLK16 ? u : 0)];
+        }
+    };
+
+    f32x16 acc[MF][2];
+#pragma unroll
+    for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    load_w(0, 0);
+    load_act(0);
+    const int m0 = wm * MF * 32;
+    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+        lds_barrier();                      // previous chunk's MFMAs are done with the images
+#pragma unroll
+        for (int it = 0; it < AITER; ++it) {
+            const int idx = tid + it * 256;
+            bf16x8 vh, vl;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v = araw[it][i];
+                v = v > 0.f ? v : v * a.slope;                    // F.leaky_relu(x, slope)
+                __bf16 h, l;
+                split_bf16(v, h, l);
+                vh[i] = h;
+                vl[i] = l;
+            }
+            if (idx < NKG * NPX) {
+                s_ah[idx] = *reinterpret_cast<u32x4 *>(&vh);
+                s_al[idx] = *reinterpret_cast<u32x4 *>(&vl);
+            }
+        }
+        for (int stage = 0; stage < a.nst; ++stage) {
+            if (stage > 0) lds_barrier();                         // previous stage's MFMAs are done with s_w
+#pragma unroll
+            for (int i = 0; i < WITER; ++i) {
+                const int u = tid + i * 256;
+                if (u < WBLK16) s_w[u] = wregs[i];
+            }
+            lds_barrier();
+            if (stage + 1 < a.nst) load_w(chunk, stage + 1);
+            else if (chunk + 1 < a.nchunk) load_w(chunk + 1, 0);
+            if (stage == 0 && chunk + 1 < a.nchunk) load_act(chunk + 1);
+#pragma unroll
+            for (int j = 0; j < TPS; ++j) {
+                const int off = a.halo_lo + a.toff[stage * TPS + j] + wn * 64 + l31;
+                bf16x8 wh[MF], wl[MF], xh[2], xl[2];
+#pragma unroll
+                for (int mi = 0; mi < MF; ++mi) {
+                    const int wi = (j * NKG + kgl) * MT + m0 + mi * 32 + l31;
+                    wh[mi] = *reinterpret_cast<const bf16x8 *>(&s_w[wi]);
+                    wl[mi] = *reinterpret_cast<const bf16x8 *>(&s_w[wi + TPS * NKG * MT]);
+                }
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int xi = kgl * NPX + off + ni * 32;
+                    xh[ni] = *reinterpret_cast<const bf16x8 *>(&s_ah[xi]);
+                    xl[ni] = *reinterpret_cast<const bf16x8 *>(&s_al[xi]);
+                }
+#pragma unroll
+                for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[mi], xh[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[mi], xl[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[mi], xh[ni], acc[mi][ni], 0, 0, 0);
+                    }
+            }
+        }
+    }
+
+    // ---- epilogue: bias, ResBlock residual, running sum over ResBlocks (reference operation order, fp32)
+    const size_t Lout = (size_t)a.Lin * a.S;
+    const size_t ob = (size_t)b * a.cout * Lout;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int q = q0 + wn * 64 + ni * 32 + l31;
+        if (q >= a.Lin) continue;
+#pragma unroll
+        for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) {
+                const int m = cot * MT + m0 + mi * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kgl;
+                if (m >= M) continue;
+                const int co = m / a.S, r = m - co * a.S;
+                const size_t idx = ob + (size_t)co * Lout + (size_t)q * a.S + r;
+                float v = acc[mi][ni][rg] + a.bias[co];
+                if (a.res) v = v + a.res[idx];
+                if (a.accmode == 1) v = a.accsrc[idx] + v;
+                else if (a.accmode == 2) v = __fdiv_rn(a.accsrc[idx] + v, a.div);
+                a.out[idx] = v;
+            }
+    }
+}
+
+template <int WM, int WN, int MF, int TPS, int AITER>
+static hipError_t launch_c1_cfg(const C1Args &a, hipStream_t st) {
+    constexpr int MT = WM * MF * 32, NT = WN * 64;
+    const int M = a.cout * a.S;
+    const int ncot = (M + MT - 1) / MT, ntile = (a.Lin + NT - 1) / NT;
+    const size_t smem = (size_t)2 * 2 * a.npx * 16 + (size_t)2 * TPS * 2 * MT * 16;
+    if ((size_t)2 * a.npx > (size_t)AITER * 256) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1d_mfma_kernel<WM, WN, MF, TPS, AITER>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, MF, TPS, AITER>), dim3((unsigned)(ncot * ntile * a.B)), dim3(256), smem, st, a);
+    return hipGetLastError();
+}
+
+// tiling of a layer by its row count M = cout * S (must agree with the packer below)
+struct C1Geom { int MT, NT, tps; };
+static C1Geom c1_geom(int M, int ntap_real) {
+    C1Geom g;
+    g.MT = M >= 128 ? 128 : (M >= 64 ? 64 : 32);
+    g.NT = M >= 128 ? 128 : 256;
+    g.tps = ntap_real <= 3 ? 3 : 4;
+    return g;
+}
+
+template <int TPS>
+static hipError_t launch_c1_t(const C1Args &a, hipStream_t st) {
+    const int M = a.cout * a.S;
+    const C1Geom g = c1_geom(M, TPS == 3 ? 3 : 4);
+    const int aiter = (2 * a.npx + 255) / 256;
+    if (g.MT == 128) {
+        if (aiter <= 2) return launch_c1_cfg<2, 2, 2, TPS, 2>(a, st);
+        if (aiter == 3) return launch_c1_cfg<2, 2, 2, TPS, 3>(a, st);
+    } else if (g.MT == 64) {
+        if (aiter <= 3) return launch_c1_cfg<1, 4, 2, TPS, 3>(a, st);
+    } else {
+        if (aiter <= 3) return launch_c1_cfg<1, 4, 1, TPS, 3>(a, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---- weight packer: reference layouts -> [chunk][stage][cot][split][tap][kg][MT][8] bf16 (hi, lo)
+//   mode 0: Conv1d weight [cout][cin][K]            rows m = co,        padded tap t < K: weight[co][ci][t]
+//   mode 1: ConvTranspose1d weight [cin][cout][Kt]  rows m = co*S + r,  tap t -> input offset d = t - 1:
+//           a = r + pad; j = a / S - d; k = a % S + S * j; weight[ci][co][k] if 0 <= j < Kt / S else 0
+__global__ void pack_conv1d_kernel(const float *__restrict__ w, __bf16 *__restrict__ dst, int mode, int cin, int cout, int K,
+                                   int S, int pad, int MT, int nst, int tps, int nchunk, int ncot, size_t total) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    size_t rr = t;
+    const int i = rr % 8; rr /= 8;
+    const int m = rr % MT; rr /= MT;
+    const int kg = rr % 2; rr /= 2;
+    const int tj = rr % tps; rr /= tps;
+    const int cot = rr % ncot; rr /= ncot;
+    const int stage = rr % nst; rr /= nst;
+    const int chunk = (int)rr;
+    const int ci = chunk * 16 + kg * 8 + i;
+    const int row = cot * MT + m;
+    const int tap = stage * tps + tj;
+    float v = 0.f;
+    if (ci < cin && row < cout * S) {
+        if (mode == 0) {
+            if (tap < K) v = w[((size_t)row * cin + ci) * K + tap];
+        } else {
+            const int co = row / S, r = row % S;
+            const int d = tap - 1;
+            if (tap < 3) {
+                const int a = r + pad;
+                const int j = a / S - d;
+                if (j >= 0 && j < K / S) v = w[((size_t)ci * cout + co) * K + (a % S) + S * j];
+            }
+        }
+    }
+    __bf16 hi, lo;
+    split_bf16(v, hi, lo);
+    const size_t blk = ((size_t)chunk * nst + stage) * ncot + cot;
+    const size_t blk_elems = (size_t)2 * tps * 2 * MT * 8;
+    dst[blk * blk_elems + (((size_t)(0 * tps + tj) * 2 + kg) * MT + m) * 8 + i] = hi;
+    dst[blk * blk_elems + (((size_t)(1 * tps + tj) * 2 + kg) * MT + m) * 8 + i] = lo;
+}
+
+// ---- conv_post: Conv1d(C -> 1, k) on leaky_relu(x, 0.01), then tanh  (models.py:116-118)
+__global__ void conv_post_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                                 float *__restrict__ out, int C, int L, int K, float slope) {
+    extern __shared__ float sw[];          // [C][K]
+    for (int i = threadIdx.x; i < C * K; i += 256) sw[i] = w[i];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= L) return;
+    const float *xb = x + (size_t)b * C * L;
+    float acc = bias[0];
+    const int half = (K - 1) / 2;
+    for (int c = 0; c < C; ++c) {
+        const float *row = xb + (size_t)c * L;
+        for (int k = 0; k < K; ++k) {
+            const int p = t + k - half;
+            float v = (p >= 0 && p < L) ? row[p] : 0.f;
+            v = v > 0.f ? v : v * slope;
+            acc = fmaf(sw[c * K + k], v, acc);
+        }
+    }
+    out[(size_t)b * L + t] = tanhf(acc);
+}
+
+}  // namespace gtts
+
+using namespace gtts;
+
+// ------------------------------------------------------------------------------------------------ host plan + C ABI
+static int vfail(int code, const char *fmt, ...) {       // text goes to gtts_last_error() (plan.hip)
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    return set_error(code, buf);
+}
+#define VCHK(expr)                                                                                               \
+    do {                                                                                                         \
+        hipError_t e_ = (expr);                                                                                  \
+        if (e_ != hipSuccess) return vfail(GTTS_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct VocLayer {
+    std::string name;
+    int mode;              // 0 Conv1d, 1 ConvTranspose1d
+    int cin, cout, K, dil, S, pad;
+    int ntap, nst, tps, MT;
+    int toff[C1_MAXTAP];
+    int halo_lo, halo_hi;
+    size_t w_off, b_off;   // blob offsets (packed weights, fp32 bias)
+};
+struct gtts_voc {
+    gtts_voc_cfg cfg;
+    std::vector<VocLayer> layers;       // conv_pre, then per stage: up, resblocks..., conv_post last (VALU)
+    size_t blob_bytes = 0;
+    size_t post_w_off = 0, post_b_off = 0;
+    int post_cin = 0, post_K = 7;
+    int pre = -1;
+    std::vector<int> ups;               // layer index of each upsampler
+    std::vector<std::vector<std::vector<int>>> rb;   // [stage][kernel][conv index in reference order] layer ids
+};
+
+static size_t valign(size_t x) { return (x + 255) / 256 * 256; }
+
+static int voc_add_layer(gtts_voc *v, const std::string &name, int mode, int cin, int cout, int K, int dil, int S, int pad) {
+    VocLayer L;
+    L.name = name; L.mode = mode; L.cin = cin; L.cout = cout; L.K = K; L.dil = dil; L.S = S; L.pad = pad;
+    const int real = mode == 0 ? K : 3;
+    const C1Geom g = c1_geom(cout * S, real);
+    L.tps = g.tps; L.MT = g.MT;
+    L.nst = (real + g.tps - 1) / g.tps;
+    L.ntap = L.nst * g.tps;
+    int lo = 0, hi = 0;
+    for (int t = 0; t < C1_MAXTAP; ++t) L.toff[t] = 0;
+    for (int t = 0; t < real; ++t) {
+        L.toff[t] = mode == 0 ? (t - (K - 1) / 2) * dil : t - 1;
+        lo = std::min(lo, L.toff[t]);
+        hi = std::max(hi, L.toff[t]);
+    }
+    L.halo_lo = -lo; L.halo_hi = hi;
+    const size_t nchunk = (cin + 15) / 16, ncot = ((size_t)cout * S + g.MT - 1) / g.MT;
+    L.w_off = v->blob_bytes;
+    v->blob_bytes = valign(v->blob_bytes + nchunk * L.nst * ncot * (size_t)2 * g.tps * 2 * g.MT * 16);
+    L.b_off = v->blob_bytes;
+    v->blob_bytes = valign(v->blob_bytes + (size_t)cout * 4);
+    v->layers.push_back(L);
+    return (int)v->layers.size() - 1;
+}
+
+extern "C" int gtts_voc_create(const gtts_voc_cfg *cfg, gtts_voc **out) {
+    if (!cfg || !out) return vfail(GTTS_E_NULL, "gtts_voc_create: null argument");
+    if (cfg->n_ups < 1 || cfg->n_ups > 8 || cfg->n_kernels < 1 || cfg->n_kernels > 8)
+        return vfail(GTTS_E_CONFIG, "unsupported number of upsamplers / resblock kernels");
+    if (cfg->resblock_type != 1 && cfg->resblock_type != 2) return vfail(GTTS_E_CONFIG, "resblock must be 1 or 2");
+    gtts_voc *v = new gtts_voc();
+    v->cfg = *cfg;
+    int ch = cfg->upsample_initial_channel;
+    v->pre = voc_add_layer(v, "conv_pre", 0, cfg->n_mels, ch, 7, 1, 1, 3);
+    for (int i = 0; i < cfg->n_ups; ++i) {
+        const int u = cfg->upsample_rates[i], k = cfg->upsample_kernel_sizes[i];
+        if (ch % 2 || k % u || (k - u) % 2 || k / u != 2 || (u & (u - 1))) {
+            delete v;
+            return vfail(GTTS_E_CONFIG, "upsampler %d: need kernel = 2 * rate, a power-of-two rate and even channels (k=%d, u=%d)", i, k, u);
+        }
+        char nm[64];
+        snprintf(nm, sizeof nm, "ups.%d", i);
+        v->ups.push_back(voc_add_layer(v, nm, 1, ch, ch / 2, k, 1, u, (k - u) / 2));
+        ch /= 2;
+        v->rb.emplace_back();
+        for (int j = 0; j < cfg->n_kernels; ++j) {
+            const int kk = cfg->resblock_kernel_sizes[j];
+            if (kk % 2 == 0 || kk > C1_MAXTAP - 1) { delete v; return vfail(GTTS_E_CONFIG, "resblock kernel %d unsupported", kk); }
+            std::vector<int> ids;
+            const int rbi = i * cfg->n_kernels + j;
+            const int nd = cfg->resblock_type == 1 ? 3 : 2;
+            if (cfg->resblock_type == 1) {
+                for (int d = 0; d < nd; ++d) {
+                    snprintf(nm, sizeof nm, "resblocks.%d.convs1.%d", rbi, d);
+                    ids.push_back(voc_add_layer(v, nm, 0, ch, ch, kk, cfg->resblock_dilations[j][d], 1, 0));
+                }
+                for (int d = 0; d < nd; ++d) {
+                    snprintf(nm, sizeof nm, "resblocks.%d.convs2.%d", rbi, d);
+                    ids.push_back(voc_add_layer(v, nm, 0, ch, ch, kk, 1, 1, 0));
+                }
+            } else {
+                for (int d = 0; d < nd; ++d) {
+                    snprintf(nm, sizeof nm, "resblocks.%d.convs.%d", rbi, d);
+                    ids.push_back(voc_add_layer(v, nm, 0, ch, ch, kk, cfg->resblock_dilations[j][d], 1, 0));
+                }
+            }
+            for (int id : ids)
+                if (v->layers[id].halo_lo + v->layers[id].halo_hi > 128) { delete v; return vfail(GTTS_E_CONFIG, "receptive field too wide"); }
+            v->rb.back().push_back(ids);
+        }
+    }
+    v->post_cin = ch;
+    v->post_w_off = v->blob_bytes;
+    v->blob_bytes = valign(v->blob_bytes + (size_t)ch * 7 * 4);
+    v->post_b_off = v->blob_bytes;
+    v->blob_bytes = valign(v->blob_bytes + 4);
+    *out = v;
+    return GTTS_OK;
+}
+
+extern "C" void gtts_voc_destroy(gtts_voc *v) { delete v; }
+
+// parameters in this order: for each MFMA layer (conv_pre, then per stage the upsampler and its ResBlock convs)
+// weight, bias; then conv_post.weight, conv_post.bias.  Names are the reference's module paths (models.py).
+extern "C" int gtts_voc_num_params(const gtts_voc *v) { return v ? (int)v->layers.size() * 2 + 2 : 0; }
+extern "C" int gtts_voc_param_info(const gtts_voc *v, int i, const char **name, int *rank, int dims[4]) {
+    if (!v) return vfail(GTTS_E_NULL, "null vocoder");
+    static thread_local std::string s;
+    const int n = (int)v->layers.size();
+    if (i < 0 || i >= 2 * n + 2) return vfail(GTTS_E_SHAPE, "parameter index out of range");
+    int d[4] = {1, 1, 1, 1}, rk = 1;
+    if (i < 2 * n) {
+        const VocLayer &L = v->layers[i / 2];
+        if (i % 2 == 0) {
+            s = L.name + ".weight"; rk = 3;
+            if (L.mode == 0) { d[0] = L.cout; d[1] = L.cin; } else { d[0] = L.cin; d[1] = L.cout; }
+            d[2] = L.K;
+        } else { s = L.name + ".bias"; d[0] = L.cout; }
+    } else if (i == 2 * n) { s = "conv_post.weight"; rk = 3; d[0] = 1; d[1] = v->post_cin; d[2] = v->post_K; }
+    else { s = "conv_post.bias"; d[0] = 1; }
+    if (name) *name = s.c_str();
+    if (rank) *rank = rk;
+    if (dims) for (int k = 0; k < 4; ++k) dims[k] = d[k];
+    return GTTS_OK;
+}
+extern "C" size_t gtts_voc_packed_bytes(const gtts_voc *v) { return v ? v->blob_bytes : 0; }
+
+extern "C" int gtts_voc_pack(const gtts_voc *v, const void *const *ptrs, int n_params, void *packed, gtts_stream_t stream) {
+    if (!v || !ptrs || !packed) return vfail(GTTS_E_NULL, "gtts_voc_pack: null argument");
+    if (n_params != gtts_voc_num_params(v)) return vfail(GTTS_E_PARAMS, "expected %d parameters, got %d", gtts_voc_num_params(v), n_params);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char *blob = (unsigned char *)packed;
+    VCHK(hipMemsetAsync(blob, 0, v->blob_bytes, st));
+    const int n = (int)v->layers.size();
+    for (int li = 0; li < n; ++li) {
+        const VocLayer &L = v->layers[li];
+        const float *w = (const float *)ptrs[2 * li], *bb = (const float *)ptrs[2 * li + 1];
+        if (!w || !bb) return vfail(GTTS_E_NULL, "parameter of %s is null", L.name.c_str());
+        const int nchunk = (L.cin + 15) / 16, ncot = (L.cout * L.S + L.MT - 1) / L.MT;
+        const size_t total = (size_t)nchunk * L.nst * ncot * L.tps * 2 * L.MT * 8;
+        hipLaunchKernelGGL(pack_conv1d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w,
+                           reinterpret_cast<__bf16 *>(blob + L.w_off), L.mode, L.cin, L.cout, L.K, L.S, L.pad, L.MT, L.nst, L.tps,
+                           nchunk, ncot, total);
+        VCHK(hipGetLastError());
+        VCHK(hipMemcpyAsync(blob + L.b_off, bb, (size_t)L.cout * 4, hipMemcpyDeviceToDevice, st));
+    }
+    if (!ptrs[2 * n] || !ptrs[2 * n + 1]) return vfail(GTTS_E_NULL, "conv_post parameter is null");
+    VCHK(hipMemcpyAsync(blob + v->post_w_off, ptrs[2 * n], (size_t)v->post_cin * v->post_K * 4, hipMemcpyDeviceToDevice, st));
+    VCHK(hipMemcpyAsync(blob + v->post_b_off, ptrs[2 * n + 1], 4, hipMemcpyDeviceToDevice, st));
+    return GTTS_OK;
+}
+
+// workspace: conv_pre output + per stage four buffers X (upsampled), T1, R (running ResBlock state), XS (sum)
+static size_t voc_stage_elems(const gtts_voc *v, int B, int T, int stage, int *C, size_t *L) {
+    int ch = v->cfg.upsample_initial_channel;
+    size_t len = (size_t)T;
+    for (int i = 0; i <= stage; ++i) { ch /= 2; len *= v->cfg.upsample_rates[i]; }
+    if (C) *C = ch;
+    if (L) *L = len;
+    return (size_t)B * ch * len;
+}
+extern "C" size_t gtts_voc_workspace_bytes(const gtts_voc *v, int B, int T) {
+    if (!v || B <= 0 || T <= 0) return 0;
+    size_t big = (size_t)B * v->cfg.upsample_initial_channel * T;
+    for (int i = 0; i < v->cfg.n_ups; ++i) big = std::max(big, voc_stage_elems(v, B, T, i, nullptr, nullptr));
+    return 5 * valign(big * 4);
+}
+extern "C" int gtts_voc_hop(const gtts_voc *v) {
+    if (!v) return 0;
+    int hop = 1;
+    for (int i = 0; i < v->cfg.n_ups; ++i) hop *= v->cfg.upsample_rates[i];
+    return hop;
+}
+
+static int voc_run_layer(const gtts_voc *v, const unsigned char *blob, int li, const float *x, float *out, const float *res,
+                         const float *accsrc, int accmode, float slope, int B, int Lin, hipStream_t st) {
+    const VocLayer &L = v->layers[li];
+    C1Args a;
+    a.x = x; a.out = out; a.res = res; a.accsrc = accsrc; a.w = blob + L.w_off; a.bias = (const float *)(blob + L.b_off);
+    a.B = B; a.cin = L.cin; a.cout = L.cout; a.Lin = Lin; a.S = L.S;
+    a.nchunk = (L.cin + 15) / 16; a.nst = L.nst;
+    for (int t = 0; t < C1_MAXTAP; ++t) a.toff[t] = L.toff[t];
+    a.halo_lo = L.halo_lo;
+    const C1Geom g = c1_geom(L.cout * L.S, L.mode == 0 ? L.K : 3);
+    a.npx = g.NT + L.halo_lo + L.halo_hi;
+    a.slope = slope; a.accmode = accmode; a.div = (float)v->cfg.n_kernels;
+    if ((size_t)L.cout * Lin * L.S >= ((size_t)1 << 31)) return vfail(GTTS_E_SHAPE, "%s: tensor too large", L.name.c_str());
+    const hipError_t e = L.tps == 3 ? launch_c1_t<3>(a, st) : launch_c1_t<4>(a, st);
+    if (e != hipSuccess) return vfail(GTTS_E_HIP, "conv1d %s: %s", L.name.c_str(), hipGetErrorString(e));
+    return GTTS_OK;
+}
+
+// Generator.forward (models.py:103-120): mel [B, n_mels, T] -> wav [B, 1, T * hop]
+extern "C" int gtts_voc_forward(const gtts_voc *v, const void *packed, const float *mel, float *wav, void *workspace,
+                                size_t workspace_bytes, int B, int T, gtts_stream_t stream) {
+    if (!v || !packed || !mel || !wav || !workspace) return vfail(GTTS_E_NULL, "gtts_voc_forward: null argument");
+    if (B <= 0 || T <= 0) return vfail(GTTS_E_SHAPE, "gtts_voc_forward: bad shape B=%d T=%d", B, T);
+    const size_t need = gtts_voc_workspace_bytes(v, B, T);
+    if (workspace_bytes < need) return vfail(GTTS_E_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned char *blob = (const unsigned char *)packed;
+    const size_t slot = need / 5;
+    float *buf[5];
+    for (int i = 0; i < 5; ++i) buf[i] = (float *)((unsigned char *)workspace + i * slot);
+    const float LR = 0.1f;                                        // LRELU_SLOPE (models.py:10)
+    int rc = voc_run_layer(v, blob, v->pre, mel, buf[0], nullptr, nullptr, 0, 1.0f, B, T, st);     // conv_pre (:104)
+    if (rc) return rc;
+    float *cur = buf[0];                                          // stage input
+    size_t len = (size_t)T;
+    const int nk = v->cfg.n_kernels;
+    for (int i = 0; i < v->cfg.n_ups; ++i) {
+        // four work buffers that are not `cur`
+        float *w4[4];
+        for (int k = 0, j = 0; k < 5; ++k) if (buf[k] != cur) w4[j++] = buf[k];
+        float *X = w4[0], *T1 = w4[1], *R = w4[2], *XS = w4[3];
+        // x = ups[i](leaky_relu(x, 0.1))  (:105-106).  From stage 1 on `cur` holds the ResBlock mean already.
+        rc = voc_run_layer(v, blob, v->ups[i], cur, X, nullptr, nullptr, 0, LR, B, (int)len, st);
+        if (rc) return rc;
+        len *= v->cfg.upsample_rates[i];
+        for (int j = 0; j < nk; ++j) {
+            const std::vector<int> &ids = v->rb[i][j];
+            // xs = r0; xs += r1; x = (xs + r2) / num_kernels   (a single ResBlock: x = r0 / 1 = r0)
+            const int accmode = j == 0 ? 0 : (j + 1 < nk ? 1 : 2);
+            if (v->cfg.resblock_type == 1) {
+                // ResBlock1 (:37-44): three times  xt = c2(lrelu(c1(lrelu(x))));  x = xt + x
+                for (int d = 0; d < 3; ++d) {
+                    const float *xin = d == 0 ? X : R;
+                    rc = voc_run_layer(v, blob, ids[d], xin, T1, nullptr, nullptr, 0, LR, B, (int)len, st);
+                    if (rc) return rc;
+                    const bool last = d == 2;
+                    rc = voc_run_layer(v, blob, ids[3 + d], T1, last ? XS : R, xin, last && accmode ? XS : nullptr,
+                                       last ? accmode : 0, LR, B, (int)len, st);
+                    if (rc) return rc;
+                }
+            } else {
+                // ResBlock2 (:66-71): twice  x = c(lrelu(x)) + x
+                for (int d = 0; d < 2; ++d) {
+                    const float *xin = d == 0 ? X : R;
+                    const bool last = d == 1;
+                    rc = voc_run_layer(v, blob, ids[d], xin, last ? XS : R, xin, last && accmode ? XS : nullptr,
+                                       last ? accmode : 0, LR, B, (int)len, st);
+                    if (rc) return rc;
+                }
+            }
+        }
+        cur = XS;
+    }
+    // x = tanh(conv_post(leaky_relu(x)))  (:116-118; default slope 0.01)
+    const int C = v->post_cin;
+    hipLaunchKernelGGL(conv_post_kernel, dim3((unsigned)((len + 255) / 256), B), dim3(256), (size_t)C * v->post_K * 4, st, cur,
+                       (const float *)(blob + v->post_w_off), (const float *)(blob + v->post_b_off), wav, C, (int)len, v->post_K, 0.01f);
+    VCHK(hipGetLastError());
+    return GTTS_OK;
+}
