@@ -212,6 +212,35 @@ int gtts_voc_hop(const gtts_voc *voc);          /* output samples per mel frame 
 int gtts_voc_forward(const gtts_voc *voc, const void *packed, const float *mel, float *wav, void *workspace,
                      size_t workspace_bytes, int B, int T, gtts_stream_t stream);
 
+/* ---- encoders either side of the sampling path: Grad-TTS TextEncoder (Grad-TTS/model/text_encoder.py:281-326) and DiffVC
+ * MelEncoder (DiffVC/model/encoder.py:257-284); inference only (dropout = identity) ------------------------------------- */
+typedef struct gtts_enc_cfg {
+    int mode;                 /* 0: TextEncoder (ids -> mu, logw), 1: MelEncoder (mel -> mel)                         */
+    int n_vocab;              /* 149 (TextEncoder)                                                                    */
+    int n_feats;              /* 80                                                                                   */
+    int channels;             /* n_enc_channels 192                                                                   */
+    int filter_channels;      /* 768                                                                                  */
+    int filter_channels_dp;   /* 256 (TextEncoder's DurationPredictor)                                                */
+    int n_heads;              /* 2                                                                                    */
+    int n_layers;             /* 6                                                                                    */
+    int kernel_size;          /* 3 (FFN / DurationPredictor convolutions; odd)                                        */
+    int window_size;          /* 4 (relative-position window; 0: none)                                                */
+} gtts_enc_cfg;
+typedef struct gtts_enc gtts_enc;
+int gtts_enc_create(const gtts_enc_cfg *cfg, gtts_enc **out);
+void gtts_enc_destroy(gtts_enc *enc);
+/* parameters in the reference module's registration order, names relative to the encoder module (e.g. `emb.weight`,
+ * `prenet.conv_layers.0.weight`, `encoder.attn_layers.0.emb_rel_k`, `proj_w.norm_1.gamma`) */
+int gtts_enc_num_params(const gtts_enc *enc);
+int gtts_enc_param_info(const gtts_enc *enc, int i, const char **name, int *rank, int dims[4]);
+size_t gtts_enc_packed_bytes(const gtts_enc *enc);
+int gtts_enc_pack(const gtts_enc *enc, const void *const *param_ptrs, int n_params, void *packed, gtts_stream_t stream);
+size_t gtts_enc_workspace_bytes(const gtts_enc *enc, int B, int L);
+/* mode 0: ids [B,L] int64 (device), x_mask [B,L] fp32 -> mu [B,n_feats,L], logw [B,1,L];  mel is ignored.
+ * mode 1: mel [B,n_feats,L], x_mask -> mu [B,n_feats,L] (the encoded mel); ids / logw are ignored. */
+int gtts_enc_forward(const gtts_enc *enc, const void *packed, const long long *ids, const float *mel, const float *x_mask,
+                     float *mu, float *logw, void *workspace, size_t workspace_bytes, int B, int L, gtts_stream_t stream);
+
 /* ---- debugging / tests: named intermediates of the last estimator call (keep_intermediates plans) ----- */
 int gtts_plan_num_tensors(const gtts_plan *plan);
 /* offset is in bytes into the workspace for the given (B,T); dims = {B,C,H,W}. */

@@ -29,6 +29,12 @@ class UnetCfg(ctypes.Structure):
                 ("vc_beta_max", ctypes.c_double)]
 
 
+class EncCfg(ctypes.Structure):
+    _fields_ = [("mode", ctypes.c_int), ("n_vocab", ctypes.c_int), ("n_feats", ctypes.c_int), ("channels", ctypes.c_int),
+                ("filter_channels", ctypes.c_int), ("filter_channels_dp", ctypes.c_int), ("n_heads", ctypes.c_int),
+                ("n_layers", ctypes.c_int), ("kernel_size", ctypes.c_int), ("window_size", ctypes.c_int)]
+
+
 class VocCfg(ctypes.Structure):
     _fields_ = [("n_mels", ctypes.c_int), ("upsample_initial_channel", ctypes.c_int), ("n_ups", ctypes.c_int),
                 ("upsample_rates", ctypes.c_int * 8), ("upsample_kernel_sizes", ctypes.c_int * 8),
@@ -74,6 +80,17 @@ def lib():
         L.gtts_mas_maximum_path.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, vp]
         L.gtts_expand_alignment.argtypes = [vp, vp, vp, vp, vp, f, vp, vp, vp, i, i, i, i, vp]
         L.gtts_log_prior.argtypes = [vp, vp, vp, i, i, i, i, vp]
+        L.gtts_enc_create.argtypes = [ctypes.POINTER(EncCfg), ctypes.POINTER(vp)]
+        L.gtts_enc_destroy.argtypes = [vp]
+        L.gtts_enc_destroy.restype = None
+        L.gtts_enc_num_params.argtypes = [vp]
+        L.gtts_enc_param_info.argtypes = [vp, i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(i), ctypes.POINTER(i * 4)]
+        L.gtts_enc_packed_bytes.argtypes = [vp]
+        L.gtts_enc_packed_bytes.restype = sz
+        L.gtts_enc_pack.argtypes = [vp, ctypes.POINTER(vp), i, vp, vp]
+        L.gtts_enc_workspace_bytes.argtypes = [vp, i, i]
+        L.gtts_enc_workspace_bytes.restype = sz
+        L.gtts_enc_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, vp]
         L.gtts_voc_create.argtypes = [ctypes.POINTER(VocCfg), ctypes.POINTER(vp)]
         L.gtts_voc_destroy.argtypes = [vp]
         L.gtts_voc_destroy.restype = None
@@ -524,6 +541,100 @@ class Vocoder:
             _check(lib().gtts_voc_forward(self._h, _ptr(blob), _ptr(mel), _ptr(wav), _ptr(ws), ws.numel(), B, T, _stream()),
                    "gtts_voc_forward")
         return wav
+
+
+class Encoder:
+    """Grad-TTS TextEncoder (mode 'text') / DiffVC MelEncoder (mode 'mel') on the HIP kernels (csrc/enc.hip)."""
+
+    def __init__(self, mode="text", n_vocab=149, n_feats=80, channels=192, filter_channels=768, filter_channels_dp=256,
+                 n_heads=2, n_layers=6, kernel_size=3, window_size=4):
+        self._kw = dict(mode=mode, n_vocab=n_vocab, n_feats=n_feats, channels=channels, filter_channels=filter_channels,
+                        filter_channels_dp=filter_channels_dp, n_heads=n_heads, n_layers=n_layers, kernel_size=kernel_size,
+                        window_size=window_size)
+        self.mode = mode
+        self.cfg = EncCfg({"text": 0, "mel": 1}[mode], int(n_vocab), int(n_feats), int(channels), int(filter_channels),
+                          int(filter_channels_dp), int(n_heads), int(n_layers), int(kernel_size), int(window_size or 0))
+        self._h = ctypes.c_void_p()
+        _check(lib().gtts_enc_create(ctypes.byref(self.cfg), ctypes.byref(self._h)), "gtts_enc_create")
+        self._ws = {}
+
+    def __reduce__(self):
+        return (_rebuild_enc, (self._kw,))
+
+    def __deepcopy__(self, memo):
+        return Encoder(**self._kw)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().gtts_enc_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def param_layout(self):
+        L = lib()
+        out = []
+        for k in range(L.gtts_enc_num_params(self._h)):
+            name, rank, dims = ctypes.c_char_p(), ctypes.c_int(), (ctypes.c_int * 4)()
+            _check(L.gtts_enc_param_info(self._h, k, ctypes.byref(name), ctypes.byref(rank), ctypes.byref(dims)),
+                   "gtts_enc_param_info")
+            out.append((name.value.decode(), tuple(dims[:rank.value])))
+        return out
+
+    def pack(self, state, device):
+        keep = []
+        for name, shape in self.param_layout():
+            if name not in state:
+                raise RuntimeError("state_dict is missing '%s'" % name)
+            t = state[name].detach().to(device=device, dtype=torch.float32).contiguous()
+            if tuple(t.shape) != shape:
+                raise RuntimeError("parameter %s has shape %s, expected %s" % (name, tuple(t.shape), shape))
+            keep.append(t)
+        arr = (ctypes.c_void_p * len(keep))(*[t.data_ptr() for t in keep])
+        blob = torch.empty(int(lib().gtts_enc_packed_bytes(self._h)), dtype=torch.uint8, device=device)
+        with torch.cuda.device(blob.device):
+            _check(lib().gtts_enc_pack(self._h, arr, len(keep), _ptr(blob), _stream()), "gtts_enc_pack")
+            torch.cuda.current_stream().synchronize()
+        return blob
+
+    def _workspace(self, B, L, device):
+        key = (B, L, str(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            self._ws.clear()
+            ws = torch.empty(int(lib().gtts_enc_workspace_bytes(self._h, B, L)), dtype=torch.uint8, device=device)
+            self._ws[key] = ws
+        return ws
+
+    def forward(self, blob, x, x_mask):
+        """text: x = ids [B,L] int64 -> (mu [B,n_feats,L], logw [B,1,L]);  mel: x = mel [B,n_feats,L] -> [B,n_feats,L].
+        x_mask [B,1,L] or [B,L] float."""
+        if not x.is_cuda:
+            raise RuntimeError("the encoder kernels need HIP tensors (got %s); there is no CPU fallback here" % x.device)
+        m = _f32c(x_mask, "x_mask")
+        if self.mode == "text":
+            ids = x.to(torch.int64).contiguous()
+            B, L = ids.shape
+            mel = None
+        else:
+            mel = _f32c(x, "mel")
+            B, _, L = mel.shape
+            ids = None
+        if m.numel() != B * L:
+            raise RuntimeError("x_mask must have B*L elements")
+        dev = x.device
+        mu = torch.empty((B, self.cfg.n_feats, L), dtype=torch.float32, device=dev)
+        logw = torch.empty((B, 1, L), dtype=torch.float32, device=dev) if self.mode == "text" else None
+        ws = self._workspace(B, L, dev)
+        with torch.cuda.device(dev):
+            _check(lib().gtts_enc_forward(self._h, _ptr(blob), _ptr(ids), _ptr(mel), _ptr(m), _ptr(mu), _ptr(logw), _ptr(ws),
+                                          ws.numel(), B, L, _stream()), "gtts_enc_forward")
+        return (mu, logw) if self.mode == "text" else mu
+
+
+def _rebuild_enc(kw):
+    return Encoder(**kw)
 
 
 def _rebuild_voc(kw):

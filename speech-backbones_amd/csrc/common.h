@@ -125,6 +125,12 @@ struct ConvArgs {
     const void *eres;       // EPI_ATTN: residual [B][cout][Hout][Wout]
     int nsplit;             // 2: bf16x3 (hi/lo), 1: plain bf16
     int act_bf16;           // 1: activation tensors are stored as bf16 (GTTS_PREC_BF16_STORE)
+    // EPI_STATS with the GroupNorm finalize fused in: the last workgroup of a sample to publish its partial sums (an
+    // agent-scope ticket per sample) reduces them in a fixed order and writes the per-channel scale / shift.
+    unsigned *ticket;       // [B] zero before the launch; reset to zero by the finalizing workgroup.  nullptr: not fused
+    const float *gn_gamma, *gn_beta;   // [cout]
+    float *gn_sc, *gn_sh;   // [B][cout]
+    float gn_count;         // elements per group = (cout / groups) * Hout * Wout
     int tiles_x, tiles_y;
 };
 

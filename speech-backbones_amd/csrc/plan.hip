@@ -76,6 +76,7 @@ struct Op {
     // attention
     size_t wkv_off, wq_off, wout_off, bout_off, g_off;
     int apart, ctxn;
+    int gn_op;                     // EPI_STATS conv: index of the OP_GNFIN it can absorb (-1: none)
     int use_ref;                   // conv / stats run on the reference mel geometry (ref_mask, T_ref)
     int has_tb;                    // PRO_IGLU: a time bias column is added (tb_off valid)
     std::string label;
@@ -106,6 +107,7 @@ struct gtts_plan {
     std::vector<Op> ops;
     int t_x0, t_s, t_tb, t_final_raw, t_final_sc, t_final_sh;
     int t_xtref = -1, t_cond = -1;   // DiffVC: diffused reference mel [B,1,F,T_ref], condition vector [B,dim_cond]
+    int t_ticket = -1;               // per-sample tickets of the fused GroupNorm finalize (zeroed once per call)
     int cache_Tr = -1;
     size_t fw_off, fb_off;     // final_conv weight / bias (fp32)
     // extra (non-program) launches, profiled as ops n_ops .. n_ops+3: prep_input, time_mlp, final_euler, mul_mask
@@ -182,6 +184,7 @@ static Op blank_op(int kind, const std::string &label) {
     o.lvl_in = o.lvl_out = 0; o.sc = o.sh = -1; o.tb_off = 0; o.w_off = o.b_off = 0; o.w_t = o.bias_t = -1;
     o.out = o.part = o.eh = o.esc = o.esh = o.eres = -1; o.C = 0; o.gamma_off = o.beta_off = 0;
     o.wkv_off = o.wq_off = o.wout_off = o.bout_off = o.g_off = 0; o.apart = o.ctxn = -1; o.use_ref = 0; o.has_tb = 0;
+    o.gn_op = -1;
     o.label = label;
     return o;
 }
@@ -207,6 +210,7 @@ static void add_block(gtts_plan *p, const std::string &pre, const std::string &t
     c.w_off = poff(p, pre + "block.0.weight");
     c.b_off = poff(p, pre + "block.0.bias");
     c.out = *raw; c.part = part;
+    c.gn_op = (int)p->ops.size() + 1;
     p->ops.push_back(c);
     Op g = blank_op(OP_GNFIN, tname + ".gn");
     g.part = part; g.C = cout; g.lvl_in = lvl;
@@ -314,7 +318,7 @@ static void compute_liveness(gtts_plan *p) {
     }
     const int n = (int)p->ops.size();
     // tensors used outside the op program: alive for the whole call
-    for (int t : {p->t_x0, p->t_s, p->t_tb, p->t_final_raw, p->t_final_sc, p->t_final_sh, p->t_xtref, p->t_cond}) {
+    for (int t : {p->t_x0, p->t_s, p->t_tb, p->t_final_raw, p->t_final_sc, p->t_final_sh, p->t_xtref, p->t_cond, p->t_ticket}) {
         if (t < 0) continue;
         p->tensors[t].first = -1;
         p->tensors[t].last = n + 1;
@@ -375,6 +379,7 @@ extern "C" int gtts_plan_create(const gtts_unet_cfg *cfg, gtts_plan **out) {
     p->t_x0 = add_tensor(p, "x0", TK_ACT, p->cin0, 0);
     p->t_s = multi ? add_tensor(p, "spk_s", TK_PERB, cfg->n_feats, 0) : -1;
     p->t_tb = add_tensor(p, "tb", TK_ROWS, 0, 0);
+    p->t_ticket = add_tensor(p, "gn_ticket", TK_PERB, 1, 0);
     p->tmlp.semb_off = -1;
 
     if (vc) {
@@ -810,11 +815,22 @@ static int run_ops(const RunCtx &c) {
                 a.eh = tptr(c, o.eh); a.esc = tptr(c, o.esc); a.esh = tptr(c, o.esh); a.eres = tptr(c, o.eres);
                 a.nsplit = nsplit;
                 a.act_bf16 = abf;
+                if (o.epi == EPI_STATS && o.gn_op >= 0 && !o.use_ref) {          // GroupNorm finalize rides in the epilogue
+                    const Op &gn = p->ops[o.gn_op];
+                    a.ticket = (unsigned *)tptr(c, p->t_ticket);
+                    a.gn_gamma = (const float *)(c.blob + gn.gamma_off);
+                    a.gn_beta = (const float *)(c.blob + gn.beta_off);
+                    a.gn_sc = tptr(c, gn.sc);
+                    a.gn_sh = tptr(c, gn.sh);
+                    a.gn_count = (float)((double)(o.cout / p->cfg.groups) * (double)a.Hout * (double)a.Wout);
+                }
                 hipError_t e = launch_conv(o.mode, a, c.st);
                 if (e != hipSuccess) return fail(GTTS_E_HIP, "conv %s: %s", o.label.c_str(), hipGetErrorString(e));
                 break;
             }
             case OP_GNFIN: {
+                if (oi > 0 && p->ops[oi - 1].kind == OP_CONV && p->ops[oi - 1].gn_op == (int)oi && !p->ops[oi - 1].use_ref)
+                    break;                          // done by the producing convolution's last workgroup
                 if (skip_op_mask() & 1) break;      // timing-only ablation (GTTS_SKIP_OPS), results are wrong
                 const int H = F >> o.lvl_in, W = c.T >> o.lvl_in;
                 const Tensor &pt = p->tensors[o.part];
@@ -922,6 +938,7 @@ extern "C" int gtts_estimator_forward(gtts_plan *plan, const void *packed, const
     const unsigned char *blob = (const unsigned char *)packed;
     RunCtx c{p, blob, (unsigned char *)workspace, mask, B, T, nullptr, 0, st};
     const int F = p->cfg.n_feats;
+    HIPCHK(hipMemsetAsync(tptr(c, p->t_ticket), 0, (size_t)B * 4, st));      // tickets of the fused GroupNorm finalize
     float *s = nullptr;
     if (multi) {
         s = tptr(c, p->t_s);
@@ -998,6 +1015,8 @@ static int enqueue_reverse_diffusion(gtts_plan *p, const void *packed, const flo
     const float h = (float)hd;
     const float bmin = p->cfg.beta_min, bdiff = (float)((double)p->cfg.beta_max - (double)p->cfg.beta_min);
     auto steps = [&]() -> int {
+        for (int hh = 0; hh < nhalf; ++hh)
+            if (hv[hh].c.B > 0) HIPCHK(hipMemsetAsync(tptr(hv[hh].c, p->t_ticket), 0, (size_t)hv[hh].c.B * 4, hv[hh].c.st));
         if (multi) {
             for (int hh = 0; hh < nhalf; ++hh) {
                 Half &H = hv[hh];
@@ -1142,6 +1161,7 @@ extern "C" int gtts_vc_estimator_forward(gtts_plan *plan, const void *packed, co
     RunCtx cx{p, blob, (unsigned char *)workspace, x_mask, B, T, nullptr, 0, st};
     cx.ref_mask = ref_mask; cx.Tr = T_ref; cx.in_x = x; cx.in_mean = mean; cx.in_c = c;
     const int F = p->cfg.n_feats;
+    HIPCHK(hipMemsetAsync(tptr(cx, p->t_ticket), 0, (size_t)B * 4, st));
     float *tb = tptr(cx, p->t_tb);
     { ProfScope ps_(p, st, (int)p->ops.size() + XOP_TIME); HIPCHK(launch_time_mlp(t, (const float *)(blob + p->freq_off), p->cfg.pe_scale, blob, p->tmlp, tb, B, st)); }
     cx.tb_row = tb;
@@ -1187,6 +1207,7 @@ extern "C" int gtts_vc_reverse_diffusion(gtts_plan *plan, const void *packed, co
     RunCtx cx{p, blob, (unsigned char *)workspace, mask, B, T, nullptr, 0, st};
     cx.ref_mask = ref_mask; cx.Tr = T_ref; cx.in_mean = mean; cx.in_c = c; cx.in_x = out;
     const int F = cf.n_feats, N = n_timesteps;
+    HIPCHK(hipMemsetAsync(tptr(cx, p->t_ticket), 0, (size_t)B * 4, st));
     // step times t_i = 1 - i*h (left endpoint, diffusion.py:170) -> fp32 `time` tensor values, all rows in one launch
     float *tb = tptr(cx, p->t_tb);
     float *tvals = tb + (size_t)std::max(B, 4096) * p->tmlp.tb_stride;

@@ -21,262 +21,10 @@
 
 #include "../../include/gradtts_abi.h"
 #include "common.h"
+#include "conv1d.h"
 #include "kernels.h"
 
 namespace gtts {
-
-constexpr int C1_MAXTAP = 12;
-struct C1Args {
-    const float *x;          // [B][cin][Lin]
-    float *out;              // [B][cout][Lin * S]
-    const float *res;        // residual added to the result (same indexing as out) or nullptr
-    const float *accsrc;     // running sum over ResBlocks (accmode 1 / 2) or nullptr
-    const unsigned char *w;  // packed [chunk][stage][cot][split][tap][kg][MT][8] bf16
-    const float *bias;       // [cout]
-    int B, cin, cout, Lin, S;
-    int nchunk, nst;
-    int toff[C1_MAXTAP];     // input offset of padded tap t (zero-weight pad taps use offset 0)
-    int halo_lo, npx;        // -min(toff);  NT + halo_lo + max(toff)
-    float slope;             // LeakyReLU slope applied to the input on load (1 = identity)
-    int accmode;             // 0 none, 1 v = accsrc + v, 2 v = (accsrc + v) / div
-    float div;
-};
-
-template <int WM, int WN, int MF, int TPS, int AITER>
-__global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const C1Args a) {
-    constexpr int MT = WM * MF * 32, NT = WN * 64, NKG = 2;
-    constexpr int WBLK16 = 2 * TPS * NKG * MT;                 // 16-byte units per weight stage (hi + lo)
-    constexpr int WITER = (WBLK16 + 255) / 256;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int NPX = a.npx;
-    u32x4 *s_ah = reinterpret_cast<u32x4 *>(smem);             // [NKG][NPX]
-    u32x4 *s_al = s_ah + NKG * NPX;
-    u32x4 *s_w = s_al + NKG * NPX;                             // [split][tap][kg][MT]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, kgl = lane >> 5;
-    const int wm = wave / WN, wn = wave % WN;
-    const int M = a.cout * a.S;
-    const int ncot = (M + MT - 1) / MT;
-    const int ntile = (a.Lin + NT - 1) / NT;
-    int wg = xcd_slot(blockIdx.x, gridDim.x);
-    const int cot = wg % ncot; wg /= ncot;
-    const int tile = wg % ntile;
-    const int b = wg / ntile;
-    const int q0 = tile * NT;
-    const float *xb = a.x + (size_t)b * a.cin * a.Lin;
-
-    // staging items: (8-channel group, halo position); geometry is chunk-invariant
-    int it_pos[AITER];
-    bool it_ok[AITER];
-#pragma unroll
-    for (int it = 0; it < AITER; ++it) {
-        const int idx = tid + it * 256;
-        const int p = idx % NPX;
-        const int t = q0 - a.halo_lo + p;
-        it_ok[it] = idx < NKG * NPX && t >= 0 && t < a.Lin;
-        it_pos[it] = it_ok[it] ? t : 0;
-    }
-    float araw[AITER][8];
-    auto load_act = [&](int chunk) {
-#pragma unroll
-        for (int it = 0; it < AITER; ++it) {
-            const int idx = tid + it * 256;
-            const int kg = min(idx / NPX, NKG - 1);
-            const int cb = chunk * 16 + kg * 8;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int c = min(cb + i, a.cin - 1);
-                const float v = xb[(size_t)c * a.Lin + it_pos[it]];
-                araw[it][i] = (it_ok[it] && cb + i < a.cin) ? v : 0.f;
-            }
-        }
-    };
-    u32x4 wregs[WITER];
-    const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(a.w);
-    auto load_w = [&](int chunk, int stage) {
-        const size_t blk = ((size_t)chunk * a.nst + stage) * ncot + cot;
-#pragma unroll
-        for (int i = 0; i < WITER; ++i) {
-            const int u = tid + i * 256;
-            wregs[i] = wsrc[blk * WBLK16 + (u < WBLK16 ? u : 0)];
-        }
-    };
-
-    f32x16 acc[MF][2];
-#pragma unroll
-    for (int mi = 0; mi < MF; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-    load_w(0, 0);
-    load_act(0);
-    const int m0 = wm * MF * 32;
-    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-        lds_barrier();                      // previous chunk's MFMAs are done with the images
-#pragma unroll
-        for (int it = 0; it < AITER; ++it) {
-            const int idx = tid + it * 256;
-            bf16x8 vh, vl;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float v = araw[it][i];
-                v = v > 0.f ? v : v * a.slope;                    // F.leaky_relu(x, slope)
-                __bf16 h, l;
-                split_bf16(v, h, l);
-                vh[i] = h;
-                vl[i] = l;
-            }
-            if (idx < NKG * NPX) {
-                s_ah[idx] = *reinterpret_cast<u32x4 *>(&vh);
-                s_al[idx] = *reinterpret_cast<u32x4 *>(&vl);
-            }
-        }
-        for (int stage = 0; stage < a.nst; ++stage) {
-            if (stage > 0) lds_barrier();                         // previous stage's MFMAs are done with s_w
-#pragma unroll
-            for (int i = 0; i < WITER; ++i) {
-                const int u = tid + i * 256;
-                if (u < WBLK16) s_w[u] = wregs[i];
-            }
-            lds_barrier();
-            if (stage + 1 < a.nst) load_w(chunk, stage + 1);
-            else if (chunk + 1 < a.nchunk) load_w(chunk + 1, 0);
-            if (stage == 0 && chunk + 1 < a.nchunk) load_act(chunk + 1);
-#pragma unroll
-            for (int j = 0; j < TPS; ++j) {
-                const int off = a.halo_lo + a.toff[stage * TPS + j] + wn * 64 + l31;
-                bf16x8 wh[MF], wl[MF], xh[2], xl[2];
-#pragma unroll
-                for (int mi = 0; mi < MF; ++mi) {
-                    const int wi = (j * NKG + kgl) * MT + m0 + mi * 32 + l31;
-                    wh[mi] = *reinterpret_cast<const bf16x8 *>(&s_w[wi]);
-                    wl[mi] = *reinterpret_cast<const bf16x8 *>(&s_w[wi + TPS * NKG * MT]);
-                }
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const int xi = kgl * NPX + off + ni * 32;
-                    xh[ni] = *reinterpret_cast<const bf16x8 *>(&s_ah[xi]);
-                    xl[ni] = *reinterpret_cast<const bf16x8 *>(&s_al[xi]);
-                }
-#pragma unroll
-                for (int mi = 0; mi < MF; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[mi], xh[ni], acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[mi], xl[ni], acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[mi], xh[ni], acc[mi][ni], 0, 0, 0);
-                    }
-            }
-        }
-    }
-
-    // ---- epilogue: bias, ResBlock residual, running sum over ResBlocks (reference operation order, fp32)
-    const size_t Lout = (size_t)a.Lin * a.S;
-    const size_t ob = (size_t)b * a.cout * Lout;
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int q = q0 + wn * 64 + ni * 32 + l31;
-        if (q >= a.Lin) continue;
-#pragma unroll
-        for (int mi = 0; mi < MF; ++mi)
-#pragma unroll
-            for (int rg = 0; rg < 16; ++rg) {
-                const int m = cot * MT + m0 + mi * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kgl;
-                if (m >= M) continue;
-                const int co = m / a.S, r = m - co * a.S;
-                const size_t idx = ob + (size_t)co * Lout + (size_t)q * a.S + r;
-                float v = acc[mi][ni][rg] + a.bias[co];
-                if (a.res) v = v + a.res[idx];
-                if (a.accmode == 1) v = a.accsrc[idx] + v;
-                else if (a.accmode == 2) v = __fdiv_rn(a.accsrc[idx] + v, a.div);
-                a.out[idx] = v;
-            }
-    }
-}
-
-template <int WM, int WN, int MF, int TPS, int AITER>
-static hipError_t launch_c1_cfg(const C1Args &a, hipStream_t st) {
-    constexpr int MT = WM * MF * 32, NT = WN * 64;
-    const int M = a.cout * a.S;
-    const int ncot = (M + MT - 1) / MT, ntile = (a.Lin + NT - 1) / NT;
-    const size_t smem = (size_t)2 * 2 * a.npx * 16 + (size_t)2 * TPS * 2 * MT * 16;
-    if ((size_t)2 * a.npx > (size_t)AITER * 256) return hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1d_mfma_kernel<WM, WN, MF, TPS, AITER>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, MF, TPS, AITER>), dim3((unsigned)(ncot * ntile * a.B)), dim3(256), smem, st, a);
-    return hipGetLastError();
-}
-
-// tiling of a layer by its row count M = cout * S (must agree with the packer below)
-struct C1Geom { int MT, NT, tps; };
-static C1Geom c1_geom(int M, int ntap_real) {
-    C1Geom g;
-    g.MT = M >= 128 ? 128 : (M >= 64 ? 64 : 32);
-    g.NT = M >= 128 ? 128 : 256;
-    g.tps = ntap_real <= 3 ? 3 : 4;
-    return g;
-}
-
-template <int TPS>
-static hipError_t launch_c1_t(const C1Args &a, hipStream_t st) {
-    const int M = a.cout * a.S;
-    const C1Geom g = c1_geom(M, TPS == 3 ? 3 : 4);
-    const int aiter = (2 * a.npx + 255) / 256;
-    if (g.MT == 128) {
-        if (aiter <= 2) return launch_c1_cfg<2, 2, 2, TPS, 2>(a, st);
-        if (aiter == 3) return launch_c1_cfg<2, 2, 2, TPS, 3>(a, st);
-    } else if (g.MT == 64) {
-        if (aiter <= 3) return launch_c1_cfg<1, 4, 2, TPS, 3>(a, st);
-    } else {
-        if (aiter <= 3) return launch_c1_cfg<1, 4, 1, TPS, 3>(a, st);
-    }
-    return hipErrorInvalidValue;
-}
-
-// ---- weight packer: reference layouts -> [chunk][stage][cot][split][tap][kg][MT][8] bf16 (hi, lo)
-//   mode 0: Conv1d weight [cout][cin][K]            rows m = co,        padded tap t < K: weight[co][ci][t]
-//   mode 1: ConvTranspose1d weight [cin][cout][Kt]  rows m = co*S + r,  tap t -> input offset d = t - 1:
-//           a = r + pad; j = a / S - d; k = a % S + S * j; weight[ci][co][k] if 0 <= j < Kt / S else 0
-__global__ void pack_conv1d_kernel(const float *__restrict__ w, __bf16 *__restrict__ dst, int mode, int cin, int cout, int K,
-                                   int S, int pad, int MT, int nst, int tps, int nchunk, int ncot, size_t total) {
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= total) return;
-    size_t rr = t;
-    const int i = rr % 8; rr /= 8;
-    const int m = rr % MT; rr /= MT;
-    const int kg = rr % 2; rr /= 2;
-    const int tj = rr % tps; rr /= tps;
-    const int cot = rr % ncot; rr /= ncot;
-    const int stage = rr % nst; rr /= nst;
-    const int chunk = (int)rr;
-    const int ci = chunk * 16 + kg * 8 + i;
-    const int row = cot * MT + m;
-    const int tap = stage * tps + tj;
-    float v = 0.f;
-    if (ci < cin && row < cout * S) {
-        if (mode == 0) {
-            if (tap < K) v = w[((size_t)row * cin + ci) * K + tap];
-        } else {
-            const int co = row / S, r = row % S;
-            const int d = tap - 1;
-            if (tap < 3) {
-                const int a = r + pad;
-                const int j = a / S - d;
-                if (j >= 0 && j < K / S) v = w[((size_t)ci * cout + co) * K + (a % S) + S * j];
-            }
-        }
-    }
-    __bf16 hi, lo;
-    split_bf16(v, hi, lo);
-    const size_t blk = ((size_t)chunk * nst + stage) * ncot + cot;
-    const size_t blk_elems = (size_t)2 * tps * 2 * MT * 8;
-    dst[blk * blk_elems + (((size_t)(0 * tps + tj) * 2 + kg) * MT + m) * 8 + i] = hi;
-    dst[blk * blk_elems + (((size_t)(1 * tps + tj) * 2 + kg) * MT + m) * 8 + i] = lo;
-}
 
 // ---- conv_post: Conv1d(C -> 1, k) on leaky_relu(x, 0.01), then tanh  (models.py:116-118)
 __global__ void conv_post_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
@@ -509,6 +257,7 @@ static int voc_run_layer(const gtts_voc *v, const unsigned char *blob, int li, c
     const C1Geom g = c1_geom(L.cout * L.S, L.mode == 0 ? L.K : 3);
     a.npx = g.NT + L.halo_lo + L.halo_hi;
     a.slope = slope; a.accmode = accmode; a.div = (float)v->cfg.n_kernels;
+    a.in_mask = nullptr; a.out_mask = nullptr;
     if ((size_t)L.cout * Lin * L.S >= ((size_t)1 << 31)) return vfail(GTTS_E_SHAPE, "%s: tensor too large", L.name.c_str());
     const hipError_t e = L.tps == 3 ? launch_c1_t<3>(a, st) : launch_c1_t<4>(a, st);
     if (e != hipSuccess) return vfail(GTTS_E_HIP, "conv1d %s: %s", L.name.c_str(), hipGetErrorString(e));

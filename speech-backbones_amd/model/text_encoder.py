@@ -1,8 +1,9 @@
 """Text encoder + duration predictor with the reference's parameter layout (Grad-TTS/model/text_encoder.py).
 
-Out of the accelerated scope (<1 % of sampling time, runs once per utterance): stock
-PyTorch-ROCm ops.  Written from the behaviour of the reference modules; parameter names / shapes are identical
-so `load_state_dict(strict=True)` of reference checkpoints works:
+Inference (eval mode, torch.no_grad, HIP tensors) runs the kernels of csrc/enc.hip through gtts_enc_forward (SURVEY.md
+section 8f rank 4); training composes the torch modules below over the same parameters.  Written from the behaviour of
+the reference modules; parameter names / shapes are identical so `load_state_dict(strict=True)` of reference checkpoints
+works:
 
   emb, prenet.{conv_layers,norm_layers}.{0,1,2}, prenet.proj, encoder.{attn_layers,norm_layers_1,ffn_layers,
   norm_layers_2}.{i}, proj_m, proj_w.{conv_1,norm_1,conv_2,norm_2,proj}
@@ -226,8 +227,32 @@ class TextEncoder(BaseModule):
                                window_size=window_size)
         self.proj_m = torch.nn.Conv1d(width, n_feats, 1)
         self.proj_w = DurationPredictor(width, filter_channels_dp, kernel_size, p_dropout)
+        self._hip_enc = None
+        self._hip_blob = None
+        self._hip_key = None
+
+    def invalidate_packed(self):
+        self._hip_blob = None
+        self._hip_key = None
+
+    def _hip_forward(self, x, x_lengths):
+        from ._backend import backend
+        be = backend()
+        if self._hip_enc is None:
+            self._hip_enc = be.Encoder("text", self.n_vocab, self.n_feats, self.n_channels, self.filter_channels,
+                                       self.filter_channels_dp, self.n_heads, self.n_layers, self.kernel_size, self.window_size)
+        params = list(self.named_parameters())
+        key = (str(x.device),) + tuple((p.data_ptr(), p._version) for _, p in params)
+        if self._hip_blob is None or self._hip_key != key:
+            self._hip_blob = self._hip_enc.pack({n: p for n, p in params}, x.device)
+            self._hip_key = key
+        x_mask = sequence_mask(x_lengths, x.shape[1]).unsqueeze(1).to(torch.float32)
+        mu, logw = self._hip_enc.forward(self._hip_blob, x, x_mask)
+        return mu, logw, x_mask
 
     def forward(self, x, x_lengths, spk=None):
+        if x.is_cuda and not torch.is_grad_enabled() and not self.training and self.n_spks == 1:
+            return self._hip_forward(x, x_lengths)
         h = (self.emb(x) * math.sqrt(self.n_channels)).transpose(1, -1)
         x_mask = sequence_mask(x_lengths, h.size(2)).unsqueeze(1).to(h.dtype)
         h = self.prenet(h, x_mask)
