@@ -241,6 +241,28 @@ size_t gtts_enc_workspace_bytes(const gtts_enc *enc, int B, int L);
 int gtts_enc_forward(const gtts_enc *enc, const void *packed, const long long *ids, const float *mel, const float *x_mask,
                      float *mu, float *logw, void *workspace, size_t workspace_bytes, int B, int L, gtts_stream_t stream);
 
+/* ---- training hot path, first kernels (Grad-TTS/train.py:105-119; Grad-TTS/model/diffusion.py:244-252,281-294) --------
+ * The host (model/_train_ops.py) wraps these in torch.autograd.Function; everything else of the backward pass is still
+ * PyTorch autograd. */
+/* Diffusion.forward_diffusion: xt = (x0 d + mu (1-d) + z sqrt(1 - e^{-cum})) mask, z_masked = z mask; d = e^{-cum/2},
+ * cum = beta_min t + (beta_max - beta_min) t^2 / 2 per sample; x0, mu, z, xt, z_masked [B,F,T], mask [B,T], t [B]. */
+int gtts_diffusion_noising(const float *x0, const float *mu, const float *z, const float *mask, const float *t, float beta_min,
+                           float beta_max, float *xt, float *z_masked, int B, int F, int T, gtts_stream_t stream);
+/* Diffusion.loss_t: r = eps sqrt(1 - e^{-cum}) + z_masked; partials[i] = sum of r^2 over 256-element blocks (fixed order;
+ * loss = sum(partials) * inv_denom with inv_denom = 1 / (sum(mask) F)); grad_eps (nullable) = d loss / d eps. */
+size_t gtts_score_loss_partials(int B, int F, int T);
+int gtts_score_loss(const float *eps, const float *z_masked, const float *t, float beta_min, float beta_max, float inv_denom,
+                    float *partials, float *grad_eps, int B, int F, int T, gtts_stream_t stream);
+/* Block's convolution for training: y = Conv2d_3x3(x * mask) + bias with weights packed by gtts_conv3x3_pack (transposed = 0);
+ * the data gradient is the same call on dy with weights packed transposed = 1 (cin / cout swapped), an all-ones mask and a
+ * zero bias; the weight / bias gradient is gtts_conv3x3_wgrad (dw, db are overwritten).  x [B,cin,H,W], mask [B,W]. */
+size_t gtts_conv3x3_packed_bytes(int cin, int cout);
+int gtts_conv3x3_pack(const float *w, void *packed, int cin, int cout, int transposed, gtts_stream_t stream);
+int gtts_conv3x3_masked(const float *x, const float *mask, const void *packed, const float *bias, float *y, int B, int cin,
+                        int cout, int H, int W, gtts_stream_t stream);
+int gtts_conv3x3_wgrad(const float *x, const float *mask, const float *dy, float *dw, float *db, int B, int cin, int cout, int H,
+                       int W, gtts_stream_t stream);
+
 /* ---- debugging / tests: named intermediates of the last estimator call (keep_intermediates plans) ----- */
 int gtts_plan_num_tensors(const gtts_plan *plan);
 /* offset is in bytes into the workspace for the given (B,T); dims = {B,C,H,W}. */

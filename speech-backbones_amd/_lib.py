@@ -80,6 +80,15 @@ def lib():
         L.gtts_mas_maximum_path.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, vp]
         L.gtts_expand_alignment.argtypes = [vp, vp, vp, vp, vp, f, vp, vp, vp, i, i, i, i, vp]
         L.gtts_log_prior.argtypes = [vp, vp, vp, i, i, i, i, vp]
+        L.gtts_diffusion_noising.argtypes = [vp, vp, vp, vp, vp, f, f, vp, vp, i, i, i, vp]
+        L.gtts_score_loss_partials.argtypes = [i, i, i]
+        L.gtts_score_loss_partials.restype = sz
+        L.gtts_score_loss.argtypes = [vp, vp, vp, f, f, f, vp, vp, i, i, i, vp]
+        L.gtts_conv3x3_packed_bytes.argtypes = [i, i]
+        L.gtts_conv3x3_packed_bytes.restype = sz
+        L.gtts_conv3x3_pack.argtypes = [vp, vp, i, i, i, vp]
+        L.gtts_conv3x3_masked.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, vp]
+        L.gtts_conv3x3_wgrad.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, vp]
         L.gtts_enc_create.argtypes = [ctypes.POINTER(EncCfg), ctypes.POINTER(vp)]
         L.gtts_enc_destroy.argtypes = [vp]
         L.gtts_enc_destroy.restype = None
@@ -684,6 +693,79 @@ def mas_maximum_path(value, mask):
         _check(lib().gtts_mas_maximum_path(_ptr(v), _ptr(m), _ptr(t_x), _ptr(t_y), _ptr(path), _ptr(scratch), b, tx,
                                            ty, _stream()), "gtts_mas_maximum_path")
     return path.to(dtype=value.dtype)
+
+
+# ---- training hot path (csrc/train.hip): raw kernels; the autograd wiring lives in model/_train_ops.py
+def conv3x3_supported(cin, cout):
+    """Channel counts the training conv kernels take (forward / data gradient / weight gradient)."""
+    def tiles(c):
+        return c == 64 or (c > 64 and c % 128 == 0)
+    return cin % 32 == 0 and cout % 32 == 0 and tiles(cin) and tiles(cout)
+
+
+def _conv3x3_run(x, mask_cols, weight, bias, transposed):
+    B, cin, H, W = x.shape
+    cout = weight.shape[1] if transposed else weight.shape[0]
+    L = lib()
+    packed = torch.empty(int(L.gtts_conv3x3_packed_bytes(cin, cout)), dtype=torch.uint8, device=x.device)
+    y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(L.gtts_conv3x3_pack(_ptr(weight), _ptr(packed), cin, cout, 1 if transposed else 0, _stream()), "gtts_conv3x3_pack")
+        _check(L.gtts_conv3x3_masked(_ptr(x), _ptr(mask_cols), _ptr(packed), _ptr(bias), _ptr(y), B, cin, cout, H, W, _stream()),
+               "gtts_conv3x3_masked")
+    return y
+
+
+def conv3x3_masked(x, mask_cols, weight, bias):
+    """Conv2d_3x3(x * mask) + bias (Block.forward, diffusion.py:56-57): x [B,cin,H,W], mask_cols [B,W], weight [cout,cin,3,3]."""
+    x, mask_cols, weight, bias = _f32c(x, "x"), _f32c(mask_cols, "mask"), _f32c(weight, "weight"), _f32c(bias, "bias")
+    return _conv3x3_run(x, mask_cols, weight, bias, False)
+
+
+def conv3x3_dgrad(dy, weight):
+    """Gradient of conv3x3_masked w.r.t. (x * mask): a 3x3 convolution of dy with the transposed, flipped weights."""
+    dy, weight = _f32c(dy, "dy"), _f32c(weight, "weight")
+    B, cout, H, W = dy.shape
+    ones = torch.ones((B, W), dtype=torch.float32, device=dy.device)
+    zero = torch.zeros(weight.shape[1], dtype=torch.float32, device=dy.device)
+    return _conv3x3_run(dy, ones, weight, zero, True)
+
+
+def conv3x3_wgrad(x, mask_cols, dy):
+    """(dW [cout,cin,3,3], db [cout]) of conv3x3_masked."""
+    x, mask_cols, dy = _f32c(x, "x"), _f32c(mask_cols, "mask"), _f32c(dy, "dy")
+    B, cin, H, W = x.shape
+    cout = dy.shape[1]
+    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+    db = torch.empty((cout,), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().gtts_conv3x3_wgrad(_ptr(x), _ptr(mask_cols), _ptr(dy), _ptr(dw), _ptr(db), B, cin, cout, H, W, _stream()),
+               "gtts_conv3x3_wgrad")
+    return dw, db
+
+
+def diffusion_noising(x0, mu, z, mask, t, beta_min, beta_max):
+    """Diffusion.forward_diffusion given the N(0,1) draw z: (xt, z * mask)   (diffusion.py:244-252)."""
+    x0, mu, z, mask, t = (_f32c(v, n) for v, n in ((x0, "x0"), (mu, "mu"), (z, "z"), (mask, "mask"), (t, "t")))
+    B, F, T = x0.shape
+    xt, zm = torch.empty_like(x0), torch.empty_like(x0)
+    with torch.cuda.device(x0.device):
+        _check(lib().gtts_diffusion_noising(_ptr(x0), _ptr(mu), _ptr(z), _ptr(mask), _ptr(t), float(beta_min), float(beta_max),
+                                            _ptr(xt), _ptr(zm), B, F, T, _stream()), "gtts_diffusion_noising")
+    return xt, zm
+
+
+def score_loss(eps, z_masked, t, beta_min, beta_max, inv_denom, want_grad=True):
+    """Diffusion.loss_t's reduction: (sum((eps s + z)^2) * inv_denom as a 0-d tensor, d loss / d eps or None)."""
+    eps, z_masked, t = _f32c(eps, "eps"), _f32c(z_masked, "z"), _f32c(t, "t")
+    B, F, T = eps.shape
+    n = int(lib().gtts_score_loss_partials(B, F, T))
+    part = torch.empty(n, dtype=torch.float32, device=eps.device)
+    g = torch.empty_like(eps) if want_grad else None
+    with torch.cuda.device(eps.device):
+        _check(lib().gtts_score_loss(_ptr(eps), _ptr(z_masked), _ptr(t), float(beta_min), float(beta_max), float(inv_denom),
+                                     _ptr(part), _ptr(g), B, F, T, _stream()), "gtts_score_loss")
+    return part.sum() * inv_denom, g
 
 
 def log_prior(mu_x, y):

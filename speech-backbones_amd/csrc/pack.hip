@@ -29,7 +29,10 @@ __global__ void pack_conv_kernel(const float *__restrict__ w, __bf16 *__restrict
     const int co = cot * MT + m;
     float v = 0.f;
     if (ci < cin && co < cout) {
-        if (mode == CONV_C3 || mode == CONV_DN) {
+        if (mode == CONV_C3 + 16) {
+            // data-gradient convolution of a 3x3 conv: W'[co'][ci'][ky][kx] = W[ci'][co'][2-ky][2-kx], W stored [cout_orig = cin][cin_orig = cout]
+            v = w[(((size_t)ci * cout + co) * 3 + (2 - stage)) * 3 + (2 - tap)];
+        } else if (mode == CONV_C3 || mode == CONV_DN) {
             v = w[(((size_t)co * cin + ci) * 3 + stage) * 3 + tap];          // ky = stage, kx = tap
         } else if (mode == CONV_P1) {
             v = w[(size_t)co * cin + ci];
@@ -50,11 +53,13 @@ __global__ void pack_conv_kernel(const float *__restrict__ w, __bf16 *__restrict
     dst[e_lo] = lo;
 }
 
+// mode CONV_C3 + 16: the transposed / flipped packing of a 3x3 conv for its data gradient (cin, cout are those of the
+// gradient convolution, i.e. swapped with respect to the forward weight tensor)
 hipError_t launch_pack_conv(int mode, const float *w, unsigned char *dst, int cin, int cout, hipStream_t st) {
-    ConvGeom g = conv_geom(mode, cin, cout);
+    ConvGeom g = conv_geom(mode & 15, cin, cout);
     const int nkg = 2 * g.kch;
     const int nchunk = (cin + 8 * nkg - 1) / (8 * nkg), ncot = (cout + g.MT - 1) / g.MT;
-    const int phases = mode == CONV_UP ? 4 : 1;
+    const int phases = (mode & 15) == CONV_UP ? 4 : 1;
     const size_t total = (size_t)phases * nchunk * g.nst * ncot * g.tps * nkg * g.MT * 8;
     hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w,
                        reinterpret_cast<__bf16 *>(dst), mode, cin, cout, g.MT, g.nst, g.tps, nchunk, ncot, nkg, total);

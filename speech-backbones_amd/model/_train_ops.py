@@ -1,14 +1,60 @@
-"""Autograd composition of the score U-Net out of stock torch ops -- TRAINING ONLY.
+"""Autograd composition of the score U-Net -- TRAINING ONLY (the sampling path under torch.no_grad never comes here).
 
-The sampling path (torch.no_grad) never comes here: it runs the hand-written HIP kernels behind the C ABI and
-raises if they are unavailable.  Training (Diffusion.compute_loss -> loss_t -> estimator with autograd,
-Grad-TTS/model/diffusion.py:281-294) needs gradients w.r.t. the same nn.Parameters; until the backward
-kernels exist it is expressed with PyTorch-ROCm's differentiable ops here.
+Training (Diffusion.compute_loss -> loss_t -> estimator with autograd, Grad-TTS/model/diffusion.py:281-294) needs gradients
+w.r.t. the same nn.Parameters.  On HIP tensors the 3x3 Block convolutions -- 84 % of the network's FLOPs, forward and
+backward -- run on the hand-written kernels of csrc/train.hip (forward and data gradient on the inference MFMA kernel,
+weight gradient as an MFMA reduction over pixels) through `MaskedConv3x3`, and the loss head through `ScoreLoss`; GroupNorm,
+Mish, attention and the small convolutions are PyTorch-ROCm differentiable ops (first stage).
+On CPU tensors (tests) everything is stock torch.
 """
 import math
 
 import torch
 import torch.nn.functional as F
+
+from ._backend import backend
+
+
+class MaskedConv3x3(torch.autograd.Function):
+    """y = Conv2d_3x3(x * mask) + bias with all three gradients on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, x, mask, weight, bias):
+        be = backend()
+        cols = mask.reshape(mask.shape[0], mask.shape[-1])          # [B,1,1,W] -> [B,W]
+        ctx.save_for_backward(x, cols, weight)
+        return be.conv3x3_masked(x, cols, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        be = backend()
+        x, cols, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = be.conv3x3_dgrad(dy, weight) * cols[:, None, None, :]
+        dw, db = be.conv3x3_wgrad(x, cols, dy)
+        return dx, None, dw, db
+
+
+class ScoreLoss(torch.autograd.Function):
+    """sum((eps * sqrt(1 - e^{-cum}) + z)^2) / denom with the gradient produced in the same pass (diffusion.py:285-287)."""
+
+    @staticmethod
+    def forward(ctx, eps, z, t, beta_min, beta_max, inv_denom):
+        loss, g = backend().score_loss(eps, z, t, beta_min, beta_max, inv_denom, want_grad=True)
+        ctx.save_for_backward(g)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (g,) = ctx.saved_tensors
+        return g * dloss, None, None, None, None, None
+
+
+def _hip_conv_ok(v, conv):
+    return (v.is_cuda and v.dtype == torch.float32 and conv.kernel_size == (3, 3) and
+            backend().conv3x3_supported(conv.in_channels, conv.out_channels))
 
 
 def _mish(v):
@@ -17,7 +63,10 @@ def _mish(v):
 
 def _conv_gn_mish(blk, v, m):
     conv, norm = blk.block[0], blk.block[1]
-    y = F.conv2d(v * m, conv.weight, conv.bias, padding=1)
+    if _hip_conv_ok(v, conv):
+        y = MaskedConv3x3.apply(v.contiguous(), m, conv.weight, conv.bias)
+    else:
+        y = F.conv2d(v * m, conv.weight, conv.bias, padding=1)
     y = F.group_norm(y, norm.num_groups, norm.weight, norm.bias, norm.eps)
     return _mish(y) * m
 

@@ -270,12 +270,14 @@ class Diffusion(BaseModule):
         self.estimator._beta_range = (float(beta_min), float(beta_max))
 
     def forward_diffusion(self, x0, mask, mu, t):
-        """diffusion.py:244-252."""
+        """diffusion.py:244-252.  HIP tensors: one fused kernel after the (reference-ordered) N(0,1) draw."""
+        z = torch.randn(x0.shape, dtype=x0.dtype, device=x0.device, requires_grad=False)
+        if x0.is_cuda and not x0.requires_grad and not mu.requires_grad:
+            return backend().diffusion_noising(x0, mu, z, mask, t, self.beta_min, self.beta_max)
         time = t[:, None, None]
         cum = get_noise(time, self.beta_min, self.beta_max, cumulative=True)
         decay = torch.exp(-0.5 * cum)
         mean = x0 * decay + mu * (1.0 - decay)
-        z = torch.randn(x0.shape, dtype=x0.dtype, device=x0.device, requires_grad=False)
         xt = mean + z * torch.sqrt(1.0 - torch.exp(-cum))
         return xt * mask, z * mask
 
@@ -317,8 +319,14 @@ class Diffusion(BaseModule):
     def loss_t(self, x0, mask, mu, t, spk=None):
         """diffusion.py:281-288."""
         xt, z = self.forward_diffusion(x0, mask, mu, t)
+        est = self.estimator(xt, mask, mu, t, spk)
+        if est.is_cuda:
+            # fused loss head: squared error reduction and d loss / d est in one pass (csrc/train.hip)
+            inv_denom = 1.0 / (torch.sum(mask) * self.n_feats)
+            loss = _train_ops.ScoreLoss.apply(est.contiguous(), z, t, float(self.beta_min), float(self.beta_max), float(inv_denom))
+            return loss, xt
         cum = get_noise(t[:, None, None], self.beta_min, self.beta_max, cumulative=True)
-        eps = self.estimator(xt, mask, mu, t, spk) * torch.sqrt(1.0 - torch.exp(-cum))
+        eps = est * torch.sqrt(1.0 - torch.exp(-cum))
         loss = torch.sum((eps + z) ** 2) / (torch.sum(mask) * self.n_feats)
         return loss, xt
 
