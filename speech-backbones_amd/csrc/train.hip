@@ -35,11 +35,13 @@ __global__ void noising_kernel(const float *__restrict__ x0, const float *__rest
     const int col = (int)(i % T);
     const float tv = t[b];
     const float cum = bmin * tv + 0.5f * (bmax - bmin) * (tv * tv);
-    const float decay = expf(-0.5f * cum);
+    // correctly rounded fp32 exp (through double): 1 - e^{-cum} cancels catastrophically for t -> 0 (train.py clamps t at
+    // 1e-5), where a 1-ulp difference in expf changes the noise scale by percents
+    const float decay = (float)exp(-0.5 * (double)cum);
     const float m = mask[b * T + col];
     const float mean = x0[i] * decay + mu[i] * (1.0f - decay);
     const float zz = z[i];
-    xt[i] = (mean + zz * sqrtf(1.0f - expf(-cum))) * m;
+    xt[i] = (mean + zz * sqrtf(1.0f - (float)exp(-(double)cum))) * m;
     zm[i] = zz * m;
 }
 
@@ -54,7 +56,7 @@ __global__ void score_loss_kernel(const float *__restrict__ eps, const float *__
         const size_t b = i / ((size_t)F * T);
         const float tv = t[b];
         const float cum = bmin * tv + 0.5f * (bmax - bmin) * (tv * tv);
-        const float s = sqrtf(1.0f - expf(-cum));
+        const float s = sqrtf(1.0f - (float)exp(-(double)cum));
         const float r = eps[i] * s + z[i];
         sq = r * r;
         if (geps) geps[i] = 2.0f * r * s * inv_denom;
@@ -231,12 +233,13 @@ extern "C" size_t gtts_conv3x3_packed_bytes(int cin, int cout) {
     return (conv_packed_bytes(CONV_C3, cin, cout) + 255) / 256 * 256;
 }
 
-// transposed != 0: pack W^T with flipped taps (the data-gradient convolution): the packed conv has cin' = cout, cout' = cin
+// transposed != 0: w is the FORWARD weight [cin_of_this_conv... i.e. forward cout][forward cin = cout of this conv][3][3] and
+// is packed transposed with flipped taps (the data-gradient convolution)
 extern "C" int gtts_conv3x3_pack(const float *w, void *packed, int cin, int cout, int transposed, gtts_stream_t stream) {
     if (!w || !packed) return tfail(GTTS_E_NULL, "gtts_conv3x3_pack: null argument");
     if (cin <= 0 || cout <= 0) return tfail(GTTS_E_SHAPE, "gtts_conv3x3_pack: bad shape");
-    TCHK(transposed ? launch_pack_conv(CONV_C3 + 16, w, (unsigned char *)packed, cout, cin, (hipStream_t)stream)
-                    : launch_pack_conv(CONV_C3, w, (unsigned char *)packed, cin, cout, (hipStream_t)stream));
+    // cin / cout are those of the convolution being packed (for the data gradient: cin = forward cout, cout = forward cin)
+    TCHK(launch_pack_conv(transposed ? CONV_C3 + 16 : CONV_C3, w, (unsigned char *)packed, cin, cout, (hipStream_t)stream));
     return GTTS_OK;
 }
 

@@ -65,7 +65,8 @@ def test_noising_and_loss_kernels(S, dev):
     mean = x0 * torch.exp(-0.5 * cum) + mu * (1.0 - torch.exp(-0.5 * cum))
     xt_ref = (mean + z * torch.sqrt(1.0 - torch.exp(-cum))) * mask
     xt, zm = S._lib.diffusion_noising(x0.to(dev), mu.to(dev), z.to(dev), mask.to(dev), t.to(dev), 0.05, 20.0)
-    assert relerr(xt.cpu(), xt_ref) <= 1e-6 and torch.equal(zm.cpu(), z * mask)
+    # t = 1e-5 (the clamp of compute_loss): 1 - exp(-cum) is ill-conditioned there, in the reference too
+    assert relerr(xt.cpu(), xt_ref) <= 1e-5 and torch.equal(zm.cpu(), z * mask)
     eps = torch.randn(B, Fm, T, generator=g, requires_grad=True)
     denom = torch.sum(mask) * Fm
     loss_ref = torch.sum((eps * torch.sqrt(1.0 - torch.exp(-cum)) + z * mask) ** 2) / denom
@@ -99,7 +100,7 @@ def test_estimator_parameter_gradients_match_cpu_autograd(S, dev):
     lc.backward()
     lg = loss_of(gpu, dev)
     lg.backward()
-    assert abs(float(lg) - float(lc)) <= 1e-5 * abs(float(lc))
+    assert abs(float(lg.detach()) - float(lc.detach())) <= 1e-5 * abs(float(lc.detach()))
     worst = ("", 0.0)
     n = 0
     for (name, pc), (_, pg) in zip(cpu.named_parameters(), gpu.named_parameters()):
