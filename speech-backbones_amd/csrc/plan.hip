@@ -1000,8 +1000,10 @@ static int enqueue_reverse_diffusion(gtts_plan *p, const void *packed, const flo
     struct Half { RunCtx c; int b0; float *s; };
     Half hv[MAX_SUB];
     for (int h = 0; h < nhalf; ++h) {
-        const int b0 = std::min(B, h * Bh0);
-        const int bn = std::min(B, b0 + Bh0) - b0;
+        // balanced contiguous split (16 utterances on 3 streams: 6 + 5 + 5, not 6 + 6 + 4)
+        const int base = B / nhalf, rem = B % nhalf;
+        const int b0 = h * base + std::min(h, rem);
+        const int bn = base + (h < rem ? 1 : 0);
         hipStream_t hs = nhalf > 1 ? p->sub[h] : st;
         hv[h].c = RunCtx{p, blob, (unsigned char *)workspace + (size_t)h * ws_half, mask + (size_t)b0 * T, bn, T, nullptr, 0, hs};
         hv[h].b0 = b0;
