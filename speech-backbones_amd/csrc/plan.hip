@@ -781,6 +781,8 @@ static int run_ops(const RunCtx &c) {
     const int abf = p->cfg.precision == GTTS_PREC_BF16_STORE ? 1 : 0;
     for (size_t oi = 0; oi < p->ops.size(); ++oi) {
         const Op &o = p->ops[oi];
+        if (o.kind == OP_GNFIN && oi > 0 && p->ops[oi - 1].kind == OP_CONV && p->ops[oi - 1].gn_op == (int)oi && !p->ops[oi - 1].use_ref)
+            continue;                               // done by the producing convolution's last workgroup (no launch)
         ProfScope prof_scope(p, c.st, (int)oi);
         switch (o.kind) {
             case OP_CONV: {
@@ -829,8 +831,6 @@ static int run_ops(const RunCtx &c) {
                 break;
             }
             case OP_GNFIN: {
-                if (oi > 0 && p->ops[oi - 1].kind == OP_CONV && p->ops[oi - 1].gn_op == (int)oi && !p->ops[oi - 1].use_ref)
-                    break;                          // done by the producing convolution's last workgroup
                 if (skip_op_mask() & 1) break;      // timing-only ablation (GTTS_SKIP_OPS), results are wrong
                 const int H = F >> o.lvl_in, W = c.T >> o.lvl_in;
                 const Tensor &pt = p->tensors[o.part];
