@@ -13,7 +13,7 @@ with open(path) as f:
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
         cnt[k].add(row.get("Dispatch_Id"))
 names = sorted({c for v in agg.values() for c in v})
-print("%-52s %8s " % ("kernel", "launches") + " ".join("%22s" % n for n in names))
+print("%-72s %8s " % ("kernel", "launches") + " ".join("%22s" % n for n in names))
 key = names[0] if names else None
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get(key, 0)):
-    print("%-52s %8d " % (k[:52], len(cnt[k])) + " ".join("%22.4g" % v.get(n, 0) for n in names))
+    print("%-72s %8d " % (k, len(cnt[k])) + " ".join("%22.4g" % v.get(n, 0) for n in names))
