@@ -32,7 +32,12 @@
 #ifndef GTTS_C3_WAVES
 #define GTTS_C3_WAVES 3
 #endif
+// single-pass bf16 kernels (config 3) have half the fragment / weight-staging registers and half the LDS
+#ifndef GTTS_C3_WAVES_BF16
+#define GTTS_C3_WAVES_BF16 3
+#endif
 #define GTTS_WAVES(MODE) ((MODE) == CONV_DN ? 2 : GTTS_C3_WAVES)
+#define GTTS_WAVES_NS(MODE, NSPLIT) ((MODE) == CONV_DN ? 2 : ((NSPLIT) == 1 ? GTTS_C3_WAVES_BF16 : GTTS_C3_WAVES))
 // Diagnostics exist only in -DGTTS_DIAG builds (tools/abexp.sh, tools/trace_conv.py); the product library is compiled
 // without it and the three switches below are then forced off, whatever else is on the command line.
 // GTTS_EXP: timing-only ablations of the main loop (results are WRONG)
@@ -124,7 +129,7 @@ static inline size_t conv_smem_bytes(int npix, int nkg, int wblk16, int cin, int
 // AT = storage type of the activation tensors (float, or __bf16 for the bf16-storage mode of BASELINE config 3: every
 // activation is read / written as bf16, the accumulators and the GroupNorm statistics stay fp32).
 template <int MODE, int WM, int WN, int MF, int KCH, int PRO, int EPI, int NSPLIT, int FULLC, typename AT>
-__global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES(MODE)) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES_NS(MODE, NSPLIT)) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int AB = (int)sizeof(AT);      // bytes per stored activation
     using C = ConvCfg<MODE, WM, WN, MF, KCH>;
     constexpr int MT = C::MT, TR = C::TR, TC = C::TC, NST = C::NST, TPS = C::TPS, NKG = C::NKG;
