@@ -241,6 +241,20 @@ size_t gtts_enc_workspace_bytes(const gtts_enc *enc, int B, int L);
 int gtts_enc_forward(const gtts_enc *enc, const void *packed, const long long *ids, const float *mel, const float *x_mask,
                      float *mu, float *logw, void *workspace, size_t workspace_bytes, int B, int L, gtts_stream_t stream);
 
+/* ---- DiffVC PostNet (DiffVC/model/postnet.py:40-53; the last stage of the "average voice" encoder, vc.py:33-41):
+ * x [B,n_feats,T], mask [B,T] -> out [B,n_feats,T].  dim % 64 == 0, 8 GroupNorm groups.  Parameter names are the module's
+ * state_dict keys (`init_conv.weight`, `res_block.block1.block.0.weight` [dim,dim,7,7], ...). */
+typedef struct gtts_postnet gtts_postnet;
+int gtts_postnet_create(int dim, int n_feats, int groups, gtts_postnet **out);
+void gtts_postnet_destroy(gtts_postnet *pn);
+int gtts_postnet_num_params(const gtts_postnet *pn);
+int gtts_postnet_param_info(const gtts_postnet *pn, int i, const char **name, int *rank, int dims[4]);
+size_t gtts_postnet_packed_bytes(const gtts_postnet *pn);
+int gtts_postnet_pack(const gtts_postnet *pn, const void *const *param_ptrs, int n_params, void *packed, gtts_stream_t stream);
+size_t gtts_postnet_workspace_bytes(const gtts_postnet *pn, int B, int T);
+int gtts_postnet_forward(const gtts_postnet *pn, const void *packed, const float *x, const float *mask, float *out,
+                         void *workspace, size_t workspace_bytes, int B, int T, gtts_stream_t stream);
+
 /* ---- training hot path, first kernels (Grad-TTS/train.py:105-119; Grad-TTS/model/diffusion.py:244-252,281-294) --------
  * The host (model/_train_ops.py) wraps these in torch.autograd.Function; everything else of the backward pass is still
  * PyTorch autograd. */

@@ -68,6 +68,7 @@ def load_diffvc():
         import model  # noqa: F401
         import model.diffusion  # noqa: F401
         import model.encoder  # noqa: F401
+        import model.postnet  # noqa: F401
         mods = {k: v for k, v in sys.modules.items() if k == "model" or k.startswith("model.")}
     finally:
         sys.path.remove(path)
@@ -76,7 +77,7 @@ def load_diffvc():
         for name in stubs:
             sys.modules.pop(name, None)
     return types.SimpleNamespace(diffusion=mods["model.diffusion"], modules=mods["model.modules"],
-                                 vc=mods.get("model.vc"), encoder=mods["model.encoder"])
+                                 vc=mods.get("model.vc"), encoder=mods["model.encoder"], postnet=mods["model.postnet"])
 
 
 def load_hifigan():

@@ -100,6 +100,17 @@ def lib():
         L.gtts_enc_workspace_bytes.argtypes = [vp, i, i]
         L.gtts_enc_workspace_bytes.restype = sz
         L.gtts_enc_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, vp]
+        L.gtts_postnet_create.argtypes = [i, i, i, ctypes.POINTER(vp)]
+        L.gtts_postnet_destroy.argtypes = [vp]
+        L.gtts_postnet_destroy.restype = None
+        L.gtts_postnet_num_params.argtypes = [vp]
+        L.gtts_postnet_param_info.argtypes = [vp, i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(i), ctypes.POINTER(i * 4)]
+        L.gtts_postnet_packed_bytes.argtypes = [vp]
+        L.gtts_postnet_packed_bytes.restype = sz
+        L.gtts_postnet_pack.argtypes = [vp, ctypes.POINTER(vp), i, vp, vp]
+        L.gtts_postnet_workspace_bytes.argtypes = [vp, i, i]
+        L.gtts_postnet_workspace_bytes.restype = sz
+        L.gtts_postnet_forward.argtypes = [vp, vp, vp, vp, vp, vp, sz, i, i, vp]
         L.gtts_voc_create.argtypes = [ctypes.POINTER(VocCfg), ctypes.POINTER(vp)]
         L.gtts_voc_destroy.argtypes = [vp]
         L.gtts_voc_destroy.restype = None
@@ -640,6 +651,79 @@ class Encoder:
             _check(lib().gtts_enc_forward(self._h, _ptr(blob), _ptr(ids), _ptr(mel), _ptr(m), _ptr(mu), _ptr(logw), _ptr(ws),
                                           ws.numel(), B, L, _stream()), "gtts_enc_forward")
         return (mu, logw) if self.mode == "text" else mu
+
+
+class PostNetPlan:
+    """DiffVC PostNet (DiffVC/model/postnet.py:40-53) on the HIP kernels (csrc/postnet.hip)."""
+
+    def __init__(self, dim=128, n_feats=80, groups=8):
+        self._kw = dict(dim=int(dim), n_feats=int(n_feats), groups=int(groups))
+        self.dim, self.n_feats = int(dim), int(n_feats)
+        self._h = ctypes.c_void_p()
+        _check(lib().gtts_postnet_create(int(dim), int(n_feats), int(groups), ctypes.byref(self._h)), "gtts_postnet_create")
+        self._ws = {}
+
+    def __reduce__(self):
+        return (_rebuild_postnet, (self._kw,))
+
+    def __deepcopy__(self, memo):
+        return PostNetPlan(**self._kw)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().gtts_postnet_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def param_layout(self):
+        L = lib()
+        out = []
+        for k in range(L.gtts_postnet_num_params(self._h)):
+            name, rank, dims = ctypes.c_char_p(), ctypes.c_int(), (ctypes.c_int * 4)()
+            _check(L.gtts_postnet_param_info(self._h, k, ctypes.byref(name), ctypes.byref(rank), ctypes.byref(dims)),
+                   "gtts_postnet_param_info")
+            out.append((name.value.decode(), tuple(dims[:rank.value])))
+        return out
+
+    def pack(self, state, device):
+        keep = []
+        for name, shape in self.param_layout():
+            if name not in state:
+                raise RuntimeError("state_dict is missing '%s'" % name)
+            t = state[name].detach().to(device=device, dtype=torch.float32).contiguous()
+            if tuple(t.shape) != shape:
+                raise RuntimeError("parameter %s has shape %s, expected %s" % (name, tuple(t.shape), shape))
+            keep.append(t)
+        arr = (ctypes.c_void_p * len(keep))(*[t.data_ptr() for t in keep])
+        blob = torch.empty(int(lib().gtts_postnet_packed_bytes(self._h)), dtype=torch.uint8, device=device)
+        with torch.cuda.device(blob.device):
+            _check(lib().gtts_postnet_pack(self._h, arr, len(keep), _ptr(blob), _stream()), "gtts_postnet_pack")
+            torch.cuda.current_stream().synchronize()
+        return blob
+
+    def forward(self, blob, x, mask):
+        """x [B,n_feats,T], mask [B,1,T] -> [B,n_feats,T]."""
+        x, mask = _f32c(x, "x"), _f32c(mask, "mask")
+        B, F, T = x.shape
+        if F != self.n_feats or mask.numel() != B * T:
+            raise RuntimeError("shape mismatch: x %s mask %s" % (tuple(x.shape), tuple(mask.shape)))
+        key = (B, T, str(x.device))
+        ws = self._ws.get(key)
+        if ws is None:
+            self._ws.clear()
+            ws = torch.empty(int(lib().gtts_postnet_workspace_bytes(self._h, B, T)), dtype=torch.uint8, device=x.device)
+            self._ws[key] = ws
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _check(lib().gtts_postnet_forward(self._h, _ptr(blob), _ptr(x), _ptr(mask), _ptr(out), _ptr(ws), ws.numel(), B, T,
+                                              _stream()), "gtts_postnet_forward")
+        return out
+
+
+def _rebuild_postnet(kw):
+    return PostNetPlan(**kw)
 
 
 def _rebuild_enc(kw):

@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["plan.hip", "conv_mfma.hip", "attn.hip", "misc.hip", "pack.hip", "mas.hip", "vc.hip", "glue.hip", "voc.hip", "enc.hip", "train.hip"]
+SOURCES = ["plan.hip", "conv_mfma.hip", "attn.hip", "misc.hip", "pack.hip", "mas.hip", "vc.hip", "glue.hip", "voc.hip", "enc.hip", "train.hip", "postnet.hip"]
 HEADERS = ["common.h", "kernels.h", "conv1d.h", os.path.join("..", "..", "include", "gradtts_abi.h")]
 LIB = os.path.join(HERE, os.environ.get("GTTS_LIB_NAME", "libgradtts_gfx950.so"))
 

@@ -79,7 +79,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // ---------------------------------------------------------------------------------------------------
 // MFMA convolution launch descriptor (conv_mfma.hip).  One kernel family covers the 3x3 Block convs, the
 // stride-2 Downsample, the 4x4/stride-2 ConvTranspose (as four 2x2 phase convs), and every 1x1 conv.
-enum ConvMode { CONV_C3 = 0, CONV_DN = 1, CONV_UP = 2, CONV_P1 = 3 };
+enum ConvMode { CONV_C3 = 0, CONV_DN = 1, CONV_UP = 2, CONV_P1 = 3, CONV_C7 = 4 };   // C7: Conv2d 7x7 pad 3 (DiffVC PostNet)
 enum ConvPro {
     PRO_PLAIN = 0,   // v = x
     PRO_MASK = 1,    // v = x * mask                                   (Block input,    diffusion.py:57)
@@ -145,11 +145,12 @@ struct ConvGeom {
 // host helper: how a layer is tiled (must match the template instantiations in conv_mfma.hip)
 static inline ConvGeom conv_geom(int mode, int cin, int cout) {
     ConvGeom g;
-    bool wide = cout > 64;
+    bool wide = cout > 64 && mode != CONV_C7;      // the 7x7 stage (7 taps) only fits LDS with the 64-cout tile
     g.MT = wide ? 128 : 64;
     g.kch = 1;   // 16-channel chunks: measured faster than 32 (occupancy: 3 workgroups per CU beat fewer barriers)
     (void)cin;
-    if (mode == CONV_DN) { g.TR = 4; g.nst = 3; g.tps = 3; }
+    if (mode == CONV_C7) { g.TR = 8; g.nst = 7; g.tps = 7; }
+    else if (mode == CONV_DN) { g.TR = 4; g.nst = 3; g.tps = 3; }
     else if (mode == CONV_UP) { g.TR = wide ? 4 : 8; g.nst = 2; g.tps = 2; }
     else if (mode == CONV_P1) { g.TR = wide ? 4 : 8; g.nst = 1; g.tps = 1; }
     else { g.TR = wide ? 4 : 8; g.nst = 3; g.tps = 3; }

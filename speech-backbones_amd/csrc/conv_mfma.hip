@@ -100,10 +100,11 @@ struct ConvCfg {
     static constexpr int MT = WM * MF * 32;
     static constexpr int TR = WN * 2;
     static constexpr int TC = 32;
-    static constexpr int NST = MODE == CONV_P1 ? 1 : (MODE == CONV_UP ? 2 : 3);
+    static constexpr int NST = MODE == CONV_P1 ? 1 : (MODE == CONV_UP ? 2 : (MODE == CONV_C7 ? 7 : 3));
+    static constexpr int HALO = MODE == CONV_C7 ? 3 : 1;    // C3 / C7: zero padding on each side
     static constexpr int TPS = NST;
-    static constexpr int HR = MODE == CONV_P1 ? TR : (MODE == CONV_DN ? 2 * TR + 1 : TR + 2);
-    static constexpr int HC = MODE == CONV_P1 ? TC : (MODE == CONV_DN ? 2 * TC + 1 : TC + 2);
+    static constexpr int HR = MODE == CONV_P1 ? TR : (MODE == CONV_DN ? 2 * TR + 1 : TR + 2 * HALO);
+    static constexpr int HC = MODE == CONV_P1 ? TC : (MODE == CONV_DN ? 2 * TC + 1 : TC + 2 * HALO);
     static constexpr int NPIX = HR * HC;
     static constexpr int NKG = 2 * KCH;                     // 8-channel groups per chunk (chunk = 16*KCH channels)
     static constexpr int AITER = (NKG * NPIX + 255) / 256;  // (pixel, kgroup) staging items per thread
@@ -129,7 +130,7 @@ static inline size_t conv_smem_bytes(int npix, int nkg, int wblk16, int cin, int
 // AT = storage type of the activation tensors (float, or __bf16 for the bf16-storage mode of BASELINE config 3: every
 // activation is read / written as bf16, the accumulators and the GroupNorm statistics stay fp32).
 template <int MODE, int WM, int WN, int MF, int KCH, int PRO, int EPI, int NSPLIT, int FULLC, typename AT>
-__global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES_NS(MODE, NSPLIT)) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : GTTS_WAVES_NS(MODE, NSPLIT)) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int AB = (int)sizeof(AT);      // bytes per stored activation
     using C = ConvCfg<MODE, WM, WN, MF, KCH>;
     constexpr int MT = C::MT, TR = C::TR, TC = C::TC, NST = C::NST, TPS = C::TPS, NKG = C::NKG;
@@ -168,8 +169,8 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES_NS(MODE, NSPL
     const int ncot = (a.cout + MT - 1) / MT;
     const int ph_y = phase >> 1, ph_x = phase & 1;
     const int y0 = ty * TR, x0 = tx * TC;
-    const int iy0 = MODE == CONV_P1 ? y0 : (MODE == CONV_DN ? 2 * y0 - 1 : y0 - 1);
-    const int ix0 = MODE == CONV_P1 ? x0 : (MODE == CONV_DN ? 2 * x0 - 1 : x0 - 1);
+    const int iy0 = MODE == CONV_P1 ? y0 : (MODE == CONV_DN ? 2 * y0 - 1 : y0 - C::HALO);
+    const int ix0 = MODE == CONV_P1 ? x0 : (MODE == CONV_DN ? 2 * x0 - 1 : x0 - C::HALO);
     const int HWin = a.Hin * a.Win;
 
     // ---- staging items: geometry is chunk-invariant.  Out-of-image items load from offset 0 (valid memory)
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(256, PRO == PRO_IGLU ? 2 : GTTS_WAVES_NS(MODE, NSPL
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
                     const int r = wn * 2 + ni;
-                    if (MODE == CONV_C3) po[ni] = (r + stage) * HC + j;
+                    if (MODE == CONV_C3 || MODE == CONV_C7) po[ni] = (r + stage) * HC + j;
                     else if (MODE == CONV_DN) po[ni] = (2 * r + stage) * HC + (j == 1 ? 33 : (j >> 1));
                     else if (MODE == CONV_UP) {
                         int dy = ph_y == 0 ? (stage == 0 ? 0 : -1) : (stage == 0 ? 1 : 0);
@@ -747,6 +748,12 @@ hipError_t launch_conv(int mode, const ConvArgs &a, hipStream_t st) {
             if (a.pro == PRO_GN)
                 return wide ? launch_prec<CONV_C3, 2, 2, 2, PRO_GN, EPI_STATS>(a, st)
                             : launch_prec<CONV_C3, 1, 4, 2, PRO_GN, EPI_STATS>(a, st);
+            break;
+        case CONV_C7:          // DiffVC PostNet Block (postnet.py:15-23): 64-cout tiles, fp32 storage, bf16x3
+            if (a.epi != EPI_STATS || a.act_bf16 || a.nsplit != 2) break;
+            if (a.cin % 16 != 0) break;
+            if (a.pro == PRO_MASK) return launch_cfg<CONV_C7, 1, 4, 2, 1, PRO_MASK, EPI_STATS, 2, 1>(a, st);
+            if (a.pro == PRO_GN) return launch_cfg<CONV_C7, 1, 4, 2, 1, PRO_GN, EPI_STATS, 2, 1>(a, st);
             break;
         case CONV_DN:
             if (a.pro != PRO_MASK || a.epi != EPI_PLAIN) break;

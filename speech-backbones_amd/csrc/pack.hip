@@ -32,6 +32,8 @@ __global__ void pack_conv_kernel(const float *__restrict__ w, __bf16 *__restrict
         if (mode == CONV_C3 + 16) {
             // data-gradient convolution of a 3x3 conv: W'[co'][ci'][ky][kx] = W[ci'][co'][2-ky][2-kx], W stored [cout_orig = cin][cin_orig = cout]
             v = w[(((size_t)ci * cout + co) * 3 + (2 - stage)) * 3 + (2 - tap)];
+        } else if (mode == CONV_C7) {
+            v = w[(((size_t)co * cin + ci) * 7 + stage) * 7 + tap];          // ky = stage, kx = tap
         } else if (mode == CONV_C3 || mode == CONV_DN) {
             v = w[(((size_t)co * cin + ci) * 3 + stage) * 3 + tap];          // ky = stage, kx = tap
         } else if (mode == CONV_P1) {

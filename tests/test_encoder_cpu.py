@@ -66,3 +66,21 @@ def test_oracle_against_reference_live():
         mu, logw, mask = enc(ids, lens)
     mu_o, logw_o, mask_o = E.text_encoder_forward(sd, ids, lens)
     assert torch.equal(mask_o, mask) and torch.allclose(mu, mu_o, atol=1e-6) and torch.allclose(logw, logw_o, atol=1e-6)
+
+
+def test_postnet_oracle_module_and_layout():
+    """DiffVC PostNet (postnet.py:40-53): oracle vs the reference's golden output, product module state_dict == plan layout,
+    torch composition == oracle."""
+    from oracle import postnet_oracle as P
+    g = golden("postnet.npz")
+    sd = P.make_state(128, seed=0)
+    assert abs(float(sum(float(v.double().abs().sum()) for v in sd.values())) - float(g["wsum"])) <= 1e-6 * float(g["wsum"])
+    y = P.postnet_forward(sd, _t(g["x"]), _t(g["mask"]))
+    assert torch.allclose(y, _t(g["y"]), atol=2e-5)
+    S = importlib.import_module("speech-backbones_amd")
+    PN = importlib.import_module("speech-backbones_amd.diffvc.model.postnet")
+    net = PN.PostNet(128).eval()
+    net.load_state_dict(sd, strict=True)
+    assert [k for k, _ in S.PostNetPlan(128).param_layout()] == list(net.state_dict().keys())
+    with torch.enable_grad():
+        assert torch.allclose(net(_t(g["x"]), _t(g["mask"])), _t(g["y"]), atol=2e-5)

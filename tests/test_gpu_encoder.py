@@ -97,3 +97,30 @@ def test_text_encoder_module_uses_the_kernels_in_inference(S, dev):
     with torch.no_grad():
         out = menc(mel.to(dev), mm.to(dev)).cpu()
     assert relerr(out, E.mel_encoder_forward(sdm, mel, mm)) <= REL
+
+
+@pytest.mark.parametrize("B,T", [(2, 45), (1, 7), (2, 130)])
+def test_postnet_matches_reference_and_oracle(S, dev, B, T):
+    """DiffVC PostNet (7x7 MFMA convolutions with fused GroupNorm statistics, Mish-on-load, EPI_TAIL residual) against the
+    reference's golden output (B=2, T=45) and the CPU oracle at other shapes."""
+    from oracle import postnet_oracle as P
+    sd = P.make_state(128, seed=0)
+    plan = S.PostNetPlan(128)
+    blob = plan.pack(sd, dev)
+    if (B, T) == (2, 45):
+        g = golden("postnet.npz")
+        x, mask, ref = _t(g["x"]), _t(g["mask"]), _t(g["y"])
+    else:
+        gen = torch.Generator().manual_seed(T)
+        x = torch.randn(B, 80, T, generator=gen)
+        mask = E.sequence_mask(torch.tensor([T] + [max(1, T // 2)] * (B - 1)), T).unsqueeze(1).float()
+        ref = P.postnet_forward(sd, x, mask)
+    out = plan.forward(blob, x.to(dev), mask.to(dev)).cpu()
+    print("postnet B=%d T=%d rel err %.2e" % (B, T, relerr(out, ref)))
+    assert relerr(out, ref) <= REL
+    PN = importlib.import_module("speech-backbones_amd.diffvc.model.postnet")
+    net = PN.PostNet(128)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    with torch.no_grad():
+        assert relerr(net(x.to(dev), mask.to(dev)).cpu(), ref) <= REL
