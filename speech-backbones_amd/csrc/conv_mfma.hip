@@ -46,6 +46,7 @@
 #undef GTTS_EXP
 #undef GTTS_TRACE
 #undef GTTS_WDMA
+#undef GTTS_ADBUF
 #endif
 #ifndef GTTS_EXP
 #define GTTS_EXP 0
@@ -66,6 +67,15 @@
 #endif
 #ifndef GTTS_TRACE
 #define GTTS_TRACE 0
+#endif
+// GTTS_ADBUF=1 (diagnostic builds; measured, not adopted): the 128-cout 3x3 kernel double-buffers its activation image
+// (13 KB more LDS, still three workgroups per CU) and transforms / stages chunk c+1 inside the last weight stage of chunk c,
+// branch-free so that the transform shares the MFMAs' basic block.  hipcc still emits the transform as one VALU block in
+// front of the stage's MFMAs (forcing the interleave with sched_group_barrier spills at 168 VGPRs), and the variant
+// measures 256 vs 238 us on the GroupNorm-prologue kernel and 221 vs 220 us on the mask-prologue kernel: the staging phase
+// cannot be hidden inside a wave from HIP source at this register budget.
+#ifndef GTTS_ADBUF
+#define GTTS_ADBUF 0
 #endif
 #ifndef GTTS_TRACE_CIN
 #define GTTS_TRACE_CIN 128      // traced layer: cin == cout == this
@@ -115,6 +125,8 @@ struct ConvCfg {
 
 static inline int conv_npar(int pro) { return pro == PRO_GN ? 3 : (pro == PRO_IGLU ? 5 : 0); }
 template <int MODE, int WM, int FULLC>
+struct ConvAdbuf { static constexpr bool on = GTTS_ADBUF && !GTTS_TRACE && GTTS_EXP == 0 && !GTTS_WDMA && MODE == CONV_C3 && WM == 2 && FULLC; };
+template <int MODE, int WM, int FULLC>
 struct ConvWdma { static constexpr bool on = GTTS_WDMA && !GTTS_TRACE && GTTS_EXP == 0 && MODE == CONV_C3 && WM == 1 && FULLC; };
 
 static inline size_t conv_smem_bytes(int npix, int nkg, int wblk16, int cin, int pro, int mt) {
@@ -143,7 +155,9 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : GTT
     u32x4 *s_ah = reinterpret_cast<u32x4 *>(smem);      // [NKG][NPIX]  hi
     u32x4 *s_al = s_ah + NKG * NPIX;                    // [NKG][NPIX]  lo
     constexpr bool WDMA = ConvWdma<MODE, WM, FULLC>::on;
-    u32x4 *s_w = s_al + NKG * NPIX;                     // [split][tap][kg][MT]  (WDMA: two such buffers)
+    constexpr bool ADBUF = ConvAdbuf<MODE, WM, FULLC>::on;
+    constexpr int AIMG = 2 * NKG * NPIX;                // one activation image (hi + lo) in 16-byte units
+    u32x4 *s_w = s_al + NKG * NPIX + (ADBUF ? AIMG : 0);   // [split][tap][kg][MT]  (WDMA: two such buffers)
     const int cpad = a.nchunk * 8 * NKG;
     // PRO_GN: [3][cpad] scale, shift, time bias; PRO_IGLU: [5][cpad] scale_a, shift_a, time bias, scale_b, shift_b
     float *s_par = reinterpret_cast<float *>(s_w + (WDMA ? 2 : 1) * WBLK16);
@@ -317,14 +331,8 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : GTT
     const unsigned long long tr_t0 = tr_last;
 #endif
 
-    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-        GTTS_SYNC();   // previous chunk's MFMAs are done with s_a* / s_w (and s_par is written)
-        TR_MARK(0);
-#if GTTS_TRACE
-        __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0): separates the load wait (phase 7) from the transform (phase 1)
-        TR_MARK(7);
-#endif
-        // ---- transform + split + stage the activation tile of this chunk (straight-line code)
+    // ---- transform + split + stage the activation tile of a chunk (straight-line code) into image (dh, dl)
+    auto stage_act = [&](int chunk, u32x4 *dh, u32x4 *dl) {
 #pragma unroll
         for (int it = 0; it < (GTTS_EXP == 3 ? 0 : AITER); ++it) {
             const int idx = tid + it * 256;
@@ -384,12 +392,33 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : GTT
                 vh[i] = h;
                 vl[i] = l;
             }
-            if (has) {
+            if constexpr (ADBUF) {
+                // branch-free (lanes without an item write a scratch slot): keeps the transform in the MFMAs' basic block
                 const int slot = kg * NPIX + pr * HC + lc;
-                s_ah[slot] = *reinterpret_cast<u32x4 *>(&vh);
-                s_al[slot] = *reinterpret_cast<u32x4 *>(&vl);
+                u32x4 *ph = has ? dh + slot : reinterpret_cast<u32x4 *>(s_red);
+                u32x4 *pl = has ? dl + slot : reinterpret_cast<u32x4 *>(s_red) + 1;
+                *ph = *reinterpret_cast<u32x4 *>(&vh);
+                *pl = *reinterpret_cast<u32x4 *>(&vl);
+            } else if (has) {
+                const int slot = kg * NPIX + pr * HC + lc;
+                dh[slot] = *reinterpret_cast<u32x4 *>(&vh);
+                dl[slot] = *reinterpret_cast<u32x4 *>(&vl);
             }
         }
+    };
+    if constexpr (ADBUF) {
+        GTTS_SYNC();                                   // s_par is visible
+        stage_act(0, s_ah, s_al);
+        if (1 < a.nchunk) load_act(1);
+    }
+    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+        if constexpr (!ADBUF) GTTS_SYNC();   // previous chunk's MFMAs are done with s_a* / s_w (and s_par is written)
+        TR_MARK(0);
+#if GTTS_TRACE
+        __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0): separates the load wait (phase 7) from the transform (phase 1)
+        TR_MARK(7);
+#endif
+        if constexpr (!ADBUF) stage_act(chunk, s_ah, s_al);
         TR_MARK(1);
 #pragma unroll
         for (int stage = 0; stage < NST; ++stage) {
@@ -402,7 +431,7 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : GTT
                 GTTS_SYNC();
                 s_wc = s_w + ((chunk * NST + stage) & 1) * WBLK16;
             } else {
-                if (stage > 0) { GTTS_SYNC(); TR_MARK(5); }   // previous stage's MFMAs are done with s_w
+                if (stage > 0 || ADBUF) { GTTS_SYNC(); TR_MARK(5); }   // previous stage's MFMAs are done with s_w
 #pragma unroll
                 for (int i = 0; i < (GTTS_EXP == 4 ? 0 : WITER); ++i) s_w[tid + i * 256] = wregs[i];
                 TR_MARK(2);
@@ -413,8 +442,19 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : GTT
             // registers are free again, the next activation chunk (a whole chunk of MFMAs ahead)
             if (GTTS_EXP == 4) {
             } else if (stage + 1 < NST) load_w(chunk, stage + 1);
+            else if (ADBUF) load_w(min(chunk + 1, a.nchunk - 1), 0);       // unconditional: no branch inside the last stage
             else if (chunk + 1 < a.nchunk) load_w(chunk + 1, 0);
-            if (stage == 0 && chunk + 1 < a.nchunk) load_act(chunk + 1);
+            if (!ADBUF && stage == 0 && chunk + 1 < a.nchunk) load_act(chunk + 1);
+            if (ADBUF && stage == NST - 1) {
+                // next chunk's image goes to the other buffer while this stage's MFMAs run (its last readers finished two
+                // barriers ago); the chunk after that is prefetched into the freed staging registers.  Unconditional (the
+                // last chunk restages itself into the idle buffer) so that the transform shares a basic block with the
+                // MFMAs and the scheduler can place its VALU work between them.
+                const int nc = min(chunk + 1, a.nchunk - 1);
+                stage_act(nc, s_ah + ((chunk + 1) & 1) * AIMG, s_al + ((chunk + 1) & 1) * AIMG);
+                load_act(min(chunk + 2, a.nchunk - 1));
+            }
+            const u32x4 *s_xh = s_ah + (ADBUF ? (chunk & 1) * AIMG : 0), *s_xl = s_al + (ADBUF ? (chunk & 1) * AIMG : 0);
 
 #pragma unroll
             for (int j = 0; j < TPS; ++j) {
@@ -446,8 +486,8 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : GTT
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni) {
                         int xi = (kc * 2 + kg_l) * NPIX + po[ni] + l31;
-                        xh[ni] = *reinterpret_cast<const bf16x8 *>(&s_ah[xi]);
-                        if (NSPLIT > 1) xl[ni] = *reinterpret_cast<const bf16x8 *>(&s_al[xi]);
+                        xh[ni] = *reinterpret_cast<const bf16x8 *>(&s_xh[xi]);
+                        if (NSPLIT > 1) xl[ni] = *reinterpret_cast<const bf16x8 *>(&s_xl[xi]);
                     }
 #endif
 #if GTTS_EXP == 1
@@ -679,7 +719,8 @@ static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
     const size_t in_c = (size_t)(PRO == PRO_IGLU ? 2 * a.cin : std::max(a.c0, a.c1));
     if (in_c * a.Hin * a.Win * sizeof(AT) >= lim || (size_t)a.cout * a.Hout * a.Wout * sizeof(AT) >= lim) return hipErrorInvalidValue;
     size_t smem = conv_smem_bytes(C::NPIX, C::NKG, C::WBLK16, a.cin, PRO, C::MT) +
-                  (ConvWdma<MODE, WM, FULLC>::on ? (size_t)C::WBLK16 * 16 : 0);
+                  (ConvWdma<MODE, WM, FULLC>::on ? (size_t)C::WBLK16 * 16 : 0) +
+                  (ConvAdbuf<MODE, WM, FULLC>::on ? (size_t)C::NPIX * C::NKG * 16 * 2 : 0);
     // hipFuncSetAttribute is per device: remember the largest size set on each device (atomics: launches may come
     // from several host threads; setting the attribute twice is harmless)
     static std::atomic<size_t> attr_set[64];
