@@ -7,6 +7,9 @@
 // Prologue on load: LeakyReLU(slope) (slope 1 = identity, 0 = ReLU), then the [B][L] input mask.  Epilogue: bias, residual,
 // running-sum modes of the HiFi-GAN ResBlocks, output mask.  Layout [B][C][L] fp32, L fastest (coalesced along time).
 #pragma once
+#include <atomic>
+#include <type_traits>
+
 #include "common.h"
 
 namespace gtts {
@@ -26,13 +29,18 @@ struct C1Args {
     float slope;             // LeakyReLU slope applied to the input on load (1 = identity, 0 = ReLU)
     int accmode;             // 0 none, 1 v = accsrc + v, 2 v = (accsrc + v) / div
     float div;
+    int ls;                  // log2(S) (S is a power of two)
     const float *in_mask;    // [B][Lin] multiplied into the input on load (x * x_mask), or nullptr
     const float *out_mask;   // [B][Lin * S] multiplied into the result, or nullptr
 };
 
+// Occupancy by tile: the 32- and 64-row tiles (HiFi-GAN's last two stages, the encoders' small layers) are bandwidth /
+// latency bound -- a workgroup's whole life is a handful of dependent memory round trips -- and want many workgroups per CU;
+// the 128-row tile is MFMA-bound and keeps the deeper (two chunks ahead) activation prefetch instead.
 template <int WM, int WN, int MF, int TPS, int AITER>
-__global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const C1Args a) {
+__global__ __launch_bounds__(256, (WM * MF == 1) ? 4 : (WM * MF == 2 ? 3 : 2)) void conv1d_mfma_kernel(const C1Args a) {
     constexpr int MT = WM * MF * 32, NT = WN * 64, NKG = 2;
+    constexpr bool PF2 = MT >= 128;                             // activation prefetch distance 2 (else 1)
     constexpr int WBLK16 = 2 * TPS * NKG * MT;                 // 16-byte units per weight stage (hi + lo)
     constexpr int WITER = (WBLK16 + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -68,8 +76,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const C1Args a) {
     float it_m[AITER];       // input mask at the item's position
 #pragma unroll
     for (int it = 0; it < AITER; ++it) it_m[it] = a.in_mask ? a.in_mask[(size_t)b * a.Lin + it_pos[it]] : 1.f;
-    float araw[AITER][8];
-    auto load_act = [&](int chunk) {
+    // Activations are prefetched TWO chunks ahead into two statically indexed register sets: a 1-D convolution has only
+    // `taps` MFMA groups per chunk (a third of the 3x3 kernel's), so one chunk of MFMAs does not cover an HBM round trip.
+    float araw2[PF2 ? 2 : 1][AITER][8];
+    auto load_act = [&](int chunk, auto set_c) {
+        constexpr int SET = PF2 ? decltype(set_c)::value : 0;
+        float (&araw)[AITER][8] = araw2[SET];
 #pragma unroll
         for (int it = 0; it < AITER; ++it) {
             const int idx = tid + it * 256;
@@ -78,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const C1Args a) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int c = min(cb + i, a.cin - 1);
-                const float v = xb[(size_t)c * a.Lin + it_pos[it]];
+                const float v = (xb + it_pos[it])[c * a.Lin];
                 araw[it][i] = (it_ok[it] && cb + i < a.cin) ? v : 0.f;
             }
         }
@@ -103,9 +115,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const C1Args a) {
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     load_w(0, 0);
-    load_act(0);
+    load_act(0, std::integral_constant<int, 0>{});
+    if (PF2 && a.nchunk > 1) load_act(1, std::integral_constant<int, 1>{});
     const int m0 = wm * MF * 32;
-    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+    auto do_chunk = [&](int chunk, auto set_c) {
+        constexpr int SET = PF2 ? decltype(set_c)::value : 0;
+        float (&araw)[AITER][8] = araw2[SET];
         lds_barrier();                      // previous chunk's MFMAs are done with the images
 #pragma unroll
         for (int it = 0; it < AITER; ++it) {
@@ -126,6 +141,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const C1Args a) {
                 s_al[idx] = *reinterpret_cast<u32x4 *>(&vl);
             }
         }
+        if (chunk + (PF2 ? 2 : 1) < a.nchunk) load_act(chunk + (PF2 ? 2 : 1), set_c);     // the set just consumed is free again
         for (int stage = 0; stage < a.nst; ++stage) {
             if (stage > 0) lds_barrier();                         // previous stage's MFMAs are done with s_w
 #pragma unroll
@@ -136,7 +152,6 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const C1Args a) {
             lds_barrier();
             if (stage + 1 < a.nst) load_w(chunk, stage + 1);
             else if (chunk + 1 < a.nchunk) load_w(chunk + 1, 0);
-            if (stage == 0 && chunk + 1 < a.nchunk) load_act(chunk + 1);
 #pragma unroll
             for (int j = 0; j < TPS; ++j) {
                 const int off = a.halo_lo + a.toff[stage * TPS + j] + wn * 64 + l31;
@@ -163,29 +178,47 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const C1Args a) {
                     }
             }
         }
+    };
+    for (int chunk = 0; chunk < a.nchunk; chunk += 2) {
+        do_chunk(chunk, std::integral_constant<int, 0>{});
+        if (chunk + 1 < a.nchunk) do_chunk(chunk + 1, std::integral_constant<int, 1>{});
     }
 
-    // ---- epilogue: bias, ResBlock residual, running sum over ResBlocks (reference operation order, fp32)
-    const size_t Lout = (size_t)a.Lin * a.S;
+    // ---- epilogue: bias, ResBlock residual, running sum over ResBlocks (reference operation order, fp32).
+    // S is a power of two (a.ls = log2 S): row m -> (channel m >> ls, output phase m & (S-1)); 32-bit offsets inside a sample.
+    const int Lout = a.Lin << a.ls;
     const size_t ob = (size_t)b * a.cout * Lout;
+    float *outb = a.out + ob;
+    const float *resb = a.res ? a.res + ob : nullptr;
+    const float *accb = a.accsrc ? a.accsrc + ob : nullptr;
+    const float *omb = a.out_mask ? a.out_mask + (size_t)b * Lout : nullptr;
+    float bv[MF][16];
+#pragma unroll
+    for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+            const int m = cot * MT + m0 + mi * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kgl;
+            bv[mi][rg] = a.bias[min(m, M - 1) >> a.ls];
+        }
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int q = q0 + wn * 64 + ni * 32 + l31;
         if (q >= a.Lin) continue;
+        const int qs = q << a.ls;
 #pragma unroll
         for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
             for (int rg = 0; rg < 16; ++rg) {
                 const int m = cot * MT + m0 + mi * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kgl;
                 if (m >= M) continue;
-                const int co = m / a.S, r = m - co * a.S;
-                const size_t idx = ob + (size_t)co * Lout + (size_t)q * a.S + r;
-                float v = acc[mi][ni][rg] + a.bias[co];
-                if (a.res) v = v + a.res[idx];
-                if (a.accmode == 1) v = a.accsrc[idx] + v;
-                else if (a.accmode == 2) v = __fdiv_rn(a.accsrc[idx] + v, a.div);
-                if (a.out_mask) v *= a.out_mask[(size_t)b * Lout + (size_t)q * a.S + r];
-                a.out[idx] = v;
+                const int co = m >> a.ls, r = m & (a.S - 1);
+                const int idx = co * Lout + qs + r;
+                float v = acc[mi][ni][rg] + bv[mi][rg];
+                if (resb) v = v + resb[idx];
+                if (a.accmode == 1) v = accb[idx] + v;
+                else if (a.accmode == 2) v = __fdiv_rn(accb[idx] + v, a.div);
+                if (omb) v *= omb[qs + r];
+                outb[idx] = v;
             }
     }
 }
@@ -197,9 +230,18 @@ static hipError_t launch_c1_cfg(const C1Args &a, hipStream_t st) {
     const int ncot = (M + MT - 1) / MT, ntile = (a.Lin + NT - 1) / NT;
     const size_t smem = (size_t)2 * 2 * a.npx * 16 + (size_t)2 * TPS * 2 * MT * 16;
     if ((size_t)2 * a.npx > (size_t)AITER * 256) return hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1d_mfma_kernel<WM, WN, MF, TPS, AITER>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
+    // the attribute is per device and sticky: raise it once per (instance, device) to the largest image any layer needs
+    static std::atomic<unsigned long long> attr_done{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    constexpr size_t SMEM_MAX = (size_t)2 * 2 * (AITER * 128) * 16 + (size_t)2 * TPS * 2 * MT * 16;
+    if (smem > SMEM_MAX) return hipErrorInvalidValue;
+    if (!((attr_done.load(std::memory_order_relaxed) >> dev) & 1ull)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1d_mfma_kernel<WM, WN, MF, TPS, AITER>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_MAX);
+        if (e != hipSuccess) return e;
+        attr_done.fetch_or(1ull << dev, std::memory_order_relaxed);
+    }
     hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, MF, TPS, AITER>), dim3((unsigned)(ncot * ntile * a.B)), dim3(256), smem, st, a);
     return hipGetLastError();
 }
@@ -307,6 +349,9 @@ static inline hipError_t launch_conv1d(C1Args a, int mode, int K, int dil, hipSt
     }
     a.halo_lo = -lo;
     a.npx = g.NT + hi - lo;
+    a.ls = 0;
+    while ((1 << a.ls) < a.S) ++a.ls;
+    if ((1 << a.ls) != a.S) return hipErrorInvalidValue;
     if ((size_t)a.cout * a.Lin * a.S >= ((size_t)1 << 31)) return hipErrorInvalidValue;
     return g.tps == 3 ? launch_c1_t<3>(a, st) : launch_c1_t<4>(a, st);
 }

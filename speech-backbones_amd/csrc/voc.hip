@@ -26,28 +26,37 @@
 
 namespace gtts {
 
-// ---- conv_post: Conv1d(C -> 1, k) on leaky_relu(x, 0.01), then tanh  (models.py:116-118)
+// ---- conv_post: Conv1d(C -> 1, k = 7) on leaky_relu(x, 0.01), then tanh  (models.py:116-118).  Four consecutive outputs per
+// thread from three aligned 16-byte loads per channel (positions t0-4 .. t0+7); L % 4 == 0 (L = T * hop).
 __global__ void conv_post_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                                  float *__restrict__ out, int C, int L, int K, float slope) {
     extern __shared__ float sw[];          // [C][K]
     for (int i = threadIdx.x; i < C * K; i += 256) sw[i] = w[i];
     __syncthreads();
     const int b = blockIdx.y;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= L) return;
+    const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (t0 >= L) return;
     const float *xb = x + (size_t)b * C * L;
-    float acc = bias[0];
-    const int half = (K - 1) / 2;
+    const float b0 = bias[0];
+    float acc[4] = {b0, b0, b0, b0};
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int c = 0; c < C; ++c) {
-        const float *row = xb + (size_t)c * L;
-        for (int k = 0; k < K; ++k) {
-            const int p = t + k - half;
-            float v = (p >= 0 && p < L) ? row[p] : 0.f;
-            v = v > 0.f ? v : v * slope;
-            acc = fmaf(sw[c * K + k], v, acc);
+        const float *row = xb + (size_t)c * L + t0;
+        const float4 lo = t0 >= 4 ? *reinterpret_cast<const float4 *>(row - 4) : zero;
+        const float4 mid = *reinterpret_cast<const float4 *>(row);
+        const float4 hi = t0 + 8 <= L ? *reinterpret_cast<const float4 *>(row + 4) : zero;
+        float v[12] = {lo.x, lo.y, lo.z, lo.w, mid.x, mid.y, mid.z, mid.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int i = 0; i < 12; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * slope;
+        const float *wr = sw + c * K;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const float wk = wr[k];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) acc[o] = fmaf(wk, v[1 + o + k], acc[o]);     // position t0 + o + k - 3 = v[4 + o + k - 3]
         }
     }
-    out[(size_t)b * L + t] = tanhf(acc);
+    *reinterpret_cast<float4 *>(out + (size_t)b * L + t0) = make_float4(tanhf(acc[0]), tanhf(acc[1]), tanhf(acc[2]), tanhf(acc[3]));
 }
 
 }  // namespace gtts
@@ -258,6 +267,8 @@ static int voc_run_layer(const gtts_voc *v, const unsigned char *blob, int li, c
     a.npx = g.NT + L.halo_lo + L.halo_hi;
     a.slope = slope; a.accmode = accmode; a.div = (float)v->cfg.n_kernels;
     a.in_mask = nullptr; a.out_mask = nullptr;
+    a.ls = 0;
+    while ((1 << a.ls) < L.S) ++a.ls;
     if ((size_t)L.cout * Lin * L.S >= ((size_t)1 << 31)) return vfail(GTTS_E_SHAPE, "%s: tensor too large", L.name.c_str());
     const hipError_t e = L.tps == 3 ? launch_c1_t<3>(a, st) : launch_c1_t<4>(a, st);
     if (e != hipSuccess) return vfail(GTTS_E_HIP, "conv1d %s: %s", L.name.c_str(), hipGetErrorString(e));
@@ -321,7 +332,8 @@ extern "C" int gtts_voc_forward(const gtts_voc *v, const void *packed, const flo
     }
     // x = tanh(conv_post(leaky_relu(x)))  (:116-118; default slope 0.01)
     const int C = v->post_cin;
-    hipLaunchKernelGGL(conv_post_kernel, dim3((unsigned)((len + 255) / 256), B), dim3(256), (size_t)C * v->post_K * 4, st, cur,
+    if (v->post_K != 7 || len % 4 != 0) return vfail(GTTS_E_CONFIG, "conv_post needs k = 7 and a multiple-of-4 length");
+    hipLaunchKernelGGL(conv_post_kernel, dim3((unsigned)((len / 4 + 255) / 256), B), dim3(256), (size_t)C * v->post_K * 4, st, cur,
                        (const float *)(blob + v->post_w_off), (const float *)(blob + v->post_b_off), wav, C, (int)len, v->post_K, 0.01f);
     VCHK(hipGetLastError());
     return GTTS_OK;
