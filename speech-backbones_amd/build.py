@@ -7,6 +7,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["plan.hip", "conv_mfma.hip", "attn.hip", "misc.hip", "pack.hip", "mas.hip", "vc.hip", "glue.hip", "voc.hip", "enc.hip", "train.hip", "postnet.hip"]
 HEADERS = ["common.h", "kernels.h", "conv1d.h", os.path.join("..", "..", "include", "gradtts_abi.h")]
+# The SLP vectoriser packs the GroupNorm / Mish / split arithmetic of the conv prologue into v_pk_*_f32.  Beside MFMAs a
+# packed f32 op costs more issue time than the two scalar ops it replaces (MI355X guide; measured here: -1.6 % per U-Net call).
+PER_FILE_FLAGS = {"conv_mfma.hip": ["-fno-slp-vectorize"]}
 LIB = os.path.join(HERE, os.environ.get("GTTS_LIB_NAME", "libgradtts_gfx950.so"))
 
 
@@ -30,6 +33,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(bdir, src.replace(".hip", ".o"))
         objs.append(obj)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+        cmd += PER_FILE_FLAGS.get(src, [])
         cmd += os.environ.get("GTTS_EXTRA_FLAGS", "").split()
         cmd += ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:

@@ -47,9 +47,32 @@
 #undef GTTS_TRACE
 #undef GTTS_WDMA
 #undef GTTS_ADBUF
+#undef GTTS_LDS_MIN
+#endif
+// GTTS_LDS_MIN (diagnostic builds): minimum dynamic LDS bytes per workgroup, to force 1 (> 80 KB) or 2 (> 54 KB) workgroups
+// per CU when tracing the un-contended phase times
+#ifndef GTTS_LDS_MIN
+#define GTTS_LDS_MIN 0
 #endif
 #ifndef GTTS_EXP
 #define GTTS_EXP 0
+#endif
+// 0 = the round-1 conditional prefetches (kept for A/B builds only)
+#ifndef GTTS_UNCOND_PF
+#define GTTS_UNCOND_PF 1
+#endif
+// GTTS_PRIV=1 (measured, not adopted; kept buildable): private weight slices for the bf16x3 3x3 convolutions -- see the
+// kernel comment.  All parity tests pass; 4 of the 6 workgroup barriers per chunk and every wait in front of an MFMA are
+// gone, and the time does not move: 128-cout GroupNorm kernel 216 vs 221 us, 128-cout mask kernel 205 vs 205, the 64-cout
+// kernels 241 vs 231 and 211 vs 204 (they stage every weight twice), 7.40 vs 7.38 ms per U-Net call.  Together with the
+// unconditional-prefetch result (exact vmcnt, no change) this rules out waits and barriers as what holds the loop at ~80 % of
+// the matrix pipe; what is left is issue time of the non-MFMA instructions, which this variant does not reduce (it adds
+// two fragment reads per tap).
+#ifndef GTTS_PRIV
+#define GTTS_PRIV 0
+#endif
+#ifndef GTTS_PRIV_WAVES
+#define GTTS_PRIV_WAVES 3
 #endif
 #define GTTS_SYNC() do { if (GTTS_EXP != 5) lds_barrier(); } while (0)     // LDS-only fence: prefetches stay in flight
 
@@ -105,10 +128,10 @@ __device__ __forceinline__ void st_act(float v, __amdgpu_buffer_rsrc_t rs, int v
     else __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (__bf16)v), rs, voff, soff, 0);
 }
 
-template <int MODE, int WM, int WN, int MF, int KCH>
+template <int MODE, int WM, int WN, int MF, int KCH, int NF = 2>
 struct ConvCfg {
     static constexpr int MT = WM * MF * 32;
-    static constexpr int TR = WN * 2;
+    static constexpr int TR = WN * NF;
     static constexpr int TC = 32;
     static constexpr int NST = MODE == CONV_P1 ? 1 : (MODE == CONV_UP ? 2 : (MODE == CONV_C7 ? 7 : 3));
     static constexpr int HALO = MODE == CONV_C7 ? 3 : 1;    // C3 / C7: zero padding on each side
@@ -141,10 +164,21 @@ static inline size_t conv_smem_bytes(int npix, int nkg, int wblk16, int cin, int
 // zero padding of the halo is produced by the mask factor alone (out-of-image items read offset 0 and get m = 0).
 // AT = storage type of the activation tensors (float, or __bf16 for the bf16-storage mode of BASELINE config 3: every
 // activation is read / written as bf16, the accumulators and the GroupNorm statistics stay fp32).
-template <int MODE, int WM, int WN, int MF, int KCH, int PRO, int EPI, int NSPLIT, int FULLC, typename AT>
-__global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : GTTS_WAVES_NS(MODE, NSPLIT)) void conv_mfma_kernel(const ConvArgs a) {
+//
+// Wave tile: (MF x 32) output channels x (NF rows x 32 columns).  PRIV = 1 ("private weight slices", 3x3 only): every
+// wave owns MF x 32 output channels for the whole tile height (WM = 4, WN = 1 for the 128-channel tile), so the weights
+// a wave multiplies with are read by no other wave.  Each wave then copies ITS rows of the packed stage into its own
+// LDS region and nobody has to wait for anybody: the two workgroup barriers per weight stage disappear (2 barriers per
+// chunk -- around the shared activation image -- instead of 6).  LDS executes the DS operations of one wave in issue
+// order, which makes the weight path a register-free ring: right after the fragment reads of tap j are issued the
+// wave overwrites slot j with tap j of the NEXT stage (prefetched one stage ahead into wregs) and re-issues the global
+// load of the stage after that, so a weight fragment is in LDS a whole stage before its first reader and no wait on a
+// ds_write or a global load sits in front of an MFMA.
+template <int MODE, int WM, int WN, int MF, int KCH, int PRO, int EPI, int NSPLIT, int FULLC, typename AT, int NF = 2, int PRIV = 0>
+__global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PRIV ? GTTS_PRIV_WAVES : GTTS_WAVES_NS(MODE, NSPLIT))) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int AB = (int)sizeof(AT);      // bytes per stored activation
-    using C = ConvCfg<MODE, WM, WN, MF, KCH>;
+    using C = ConvCfg<MODE, WM, WN, MF, KCH, NF>;
+    static_assert(!PRIV || (MODE == CONV_C3 && FULLC && KCH == 1 && MF == 1), "private weight slices: 3x3, whole chunks, one fragment row per wave");
     constexpr int MT = C::MT, TR = C::TR, TC = C::TC, NST = C::NST, TPS = C::TPS, NKG = C::NKG;
     constexpr int HC = C::HC, NPIX = C::NPIX, AITER = C::AITER, WBLK16 = C::WBLK16, WITER = C::WITER;
 
@@ -160,7 +194,8 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : GTT
     u32x4 *s_w = s_al + NKG * NPIX + (ADBUF ? AIMG : 0);   // [split][tap][kg][MT]  (WDMA: two such buffers)
     const int cpad = a.nchunk * 8 * NKG;
     // PRO_GN: [3][cpad] scale, shift, time bias; PRO_IGLU: [5][cpad] scale_a, shift_a, time bias, scale_b, shift_b
-    float *s_par = reinterpret_cast<float *>(s_w + (WDMA ? 2 : 1) * WBLK16);
+    constexpr int WLDS16 = PRIV ? 4 * NSPLIT * TPS * NKG * MF * 32 : WBLK16;   // PRIV: four private regions
+    float *s_par = reinterpret_cast<float *>(s_w + (WDMA ? 2 : 1) * WLDS16);
     constexpr int NPAR = PRO == PRO_GN ? 3 : (PRO == PRO_IGLU ? 5 : 0);
     float *s_red = s_par + NPAR * cpad;                       // [4 waves][MF][4 octets][2]
     float *s_epi = s_red + 4 * 2 * 4 * 2;                     // [3][MT]: bias, (EPI_TAIL) GN scale, shift
@@ -262,7 +297,9 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : GTT
     };
 
     const unsigned char *wbase = a.w + (size_t)b * a.w_bstride;
-    u32x4 wregs[WITER];
+    constexpr int PSEG = NSPLIT * TPS * NKG;              // PRIV: (split, tap, kgroup) segments of MF*32 rows per wave
+    constexpr int PITER = PRIV ? PSEG * MF * 32 / 64 : 1; // 16-byte items per lane and stage (NKG = 2: item i = (split, tap) i)
+    u32x4 wregs[PRIV ? PITER : WITER];
     const int wtotal = (MODE == CONV_UP ? 4 : 1) * a.nchunk * NST * ncot * WBLK16 * 16;       // bytes of this conv's blocks
     const __amdgpu_buffer_rsrc_t rsw = uniform_rsrc(wbase, wtotal);
     auto load_w = [&](int chunk, int stage) {
@@ -281,16 +318,38 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : GTT
         }
     };
 
-    f32x16 acc[MF][2];
+    // PRIV: tap j of global stage g (= chunk * NST + stage, clamped to the last one) -> wregs[j] (hi), wregs[TPS + j] (lo)
+    u32x4 *s_wp = s_w + wave * (PSEG * MF * 32);          // this wave's private region: [split][tap][kg][MF*32 rows]
+    auto load_w_tap = [&](int g, int j) {
+        const int gl = min(g, a.nchunk * NST - 1);
+        const int blk = gl * ncot + cot;                   // phase == 0 for CONV_C3
+#pragma unroll
+        for (int sp = 0; sp < NSPLIT; ++sp) {
+            const int i = sp * TPS + j;
+            // per-lane offset shared by all items; the (split, tap) item offset rides in the scalar offset
+            wregs[i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (kg_l * MT + wm * MF * 32 + l31) * 16,
+                                                             blk * (WBLK16 * 16) + i * (NKG * MT * 16), 0);
+        }
+    };
+
+    f32x16 acc[MF][NF];
 #pragma unroll
     for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NF; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    load_w(0, 0);
-    load_act(0);
+    // (ragged-channel first layers keep the conditional form: the extra live range spills there)
+    constexpr bool UNCOND_PF = GTTS_UNCOND_PF && FULLC;
+    // activations first, weights second: the same queue order as on the loop's back edge, so the waits at the loop head
+    // are exact on both paths
+    if constexpr (PRIV) {
+        load_act(0);
+#pragma unroll
+        for (int j = 0; j < TPS; ++j) load_w_tap(0, j);
+    } else if (UNCOND_PF) { load_act(0); load_w(0, 0); }
+    else { load_w(0, 0); load_act(0); }
 
     // (filled after the first tile's loads are in flight: the parameter loads share one memory round trip with them
     // instead of adding two serialized ones in front)
@@ -406,12 +465,71 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : GTT
             }
         }
     };
+    if constexpr (PRIV) {
+        // ---- private-slice main loop: 2 workgroup barriers per chunk (both around the shared activation image)
+        // stage (0, 0) goes straight into the ring, stage (0, 1) (or (1, 0)) waits in wregs
+#pragma unroll
+        for (int i = 0; i < PITER; ++i) s_wp[i * 64 + lane] = wregs[i];
+#pragma unroll
+        for (int j = 0; j < TPS; ++j) load_w_tap(1, j);
+        int chunk = 0;
+        do {       // (bottom-tested by hand: hipcc left the exit test at the top of this loop and then copied all 64
+                   //  accumulator registers into the exit block's set and back on every iteration)
+            GTTS_SYNC();                               // every wave is done with the previous chunk's image (and s_par is written)
+            stage_act(chunk, s_ah, s_al);
+            GTTS_SYNC();
+            load_act(min(chunk + 1, a.nchunk - 1));    // unconditional: see the comment on prefetches below
+#pragma unroll
+            for (int stage = 0; stage < NST; ++stage) {
+                const int g = chunk * NST + stage;
+#pragma unroll
+                for (int j = 0; j < TPS; ++j) {
+                    bf16x8 wh[MF], wl[MF];
+#pragma unroll
+                    for (int mi = 0; mi < MF; ++mi) {
+                        const int wi = (j * NKG + kg_l) * (MF * 32) + mi * 32 + l31;
+                        wh[mi] = *reinterpret_cast<const bf16x8 *>(&s_wp[wi]);
+                        if (NSPLIT > 1) wl[mi] = *reinterpret_cast<const bf16x8 *>(&s_wp[wi + TPS * NKG * MF * 32]);
+                    }
+                    // slot j is free as soon as the reads above are ISSUED (DS operations of a wave execute in order):
+                    // refill it with tap j of the next stage, re-issue the global load of the stage after that
+#pragma unroll
+                    for (int sp = 0; sp < NSPLIT; ++sp) s_wp[(sp * TPS + j) * 64 + lane] = wregs[sp * TPS + j];
+                    load_w_tap(g + 2, j);
+#pragma unroll
+                    for (int np = 0; np < NF; np += 2) {
+                        bf16x8 xh[2], xl[2];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int r = wn * NF + np + q;
+                            const int xi = kg_l * NPIX + (r + stage) * HC + j + l31;
+                            xh[q] = *reinterpret_cast<const bf16x8 *>(&s_ah[xi]);
+                            if (NSPLIT > 1) xl[q] = *reinterpret_cast<const bf16x8 *>(&s_al[xi]);
+                        }
+#pragma unroll
+                        for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) {
+                                if (NSPLIT > 1) {
+                                    acc[mi][np + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[mi], xh[q], acc[mi][np + q], 0, 0, 0);
+                                    acc[mi][np + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[mi], xl[q], acc[mi][np + q], 0, 0, 0);
+                                }
+                                acc[mi][np + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[mi], xh[q], acc[mi][np + q], 0, 0, 0);
+                            }
+                    }
+                    // keep hipcc from hoisting the next taps' fragment reads over this tap's MFMAs: the register budget
+                    // (168 at three waves per SIMD) has room for one tap's fragments, not for two
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } while (++chunk < a.nchunk);
+    }
     if constexpr (ADBUF) {
         GTTS_SYNC();                                   // s_par is visible
         stage_act(0, s_ah, s_al);
         if (1 < a.nchunk) load_act(1);
     }
-    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+    for (int chunk = 0; chunk < (PRIV ? 0 : a.nchunk); ++chunk) {
         if constexpr (!ADBUF) GTTS_SYNC();   // previous chunk's MFMAs are done with s_a* / s_w (and s_par is written)
         TR_MARK(0);
 #if GTTS_TRACE
@@ -440,11 +558,19 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : GTT
             }
             // ---- prefetch behind the MFMAs: next weight block (one stage ahead) and, as early as the staging
             // registers are free again, the next activation chunk (a whole chunk of MFMAs ahead)
+            // Both prefetches are UNCONDITIONAL (the last chunk re-requests its own blocks; the registers are never read).
+            // A prefetch under `if (chunk + 1 < nchunk)` puts a control-flow merge between the loads and the next
+            // stage's s_waitcnt: hipcc then has to assume the shorter queue and emits vmcnt(5) for the weight stage,
+            // which also waits for 11 of the 16 activation loads issued one stage (36 MFMAs) earlier -- the HBM latency
+            // of the NEXT chunk's tile was exposed once per chunk.  Straight-line code gets the exact vmcnt(21).
             if (GTTS_EXP == 4) {
             } else if (stage + 1 < NST) load_w(chunk, stage + 1);
-            else if (ADBUF) load_w(min(chunk + 1, a.nchunk - 1), 0);       // unconditional: no branch inside the last stage
+            else if (ADBUF || UNCOND_PF) load_w(min(chunk + 1, a.nchunk - 1), 0);
             else if (chunk + 1 < a.nchunk) load_w(chunk + 1, 0);
-            if (!ADBUF && stage == 0 && chunk + 1 < a.nchunk) load_act(chunk + 1);
+            if (!ADBUF && stage == 0) {
+                if (UNCOND_PF) load_act(min(chunk + 1, a.nchunk - 1));
+                else if (chunk + 1 < a.nchunk) load_act(chunk + 1);
+            }
             if (ADBUF && stage == NST - 1) {
                 // next chunk's image goes to the other buffer while this stage's MFMAs run (its last readers finished two
                 // barriers ago); the chunk after that is prefetched into the freed staging registers.  Unconditional (the
@@ -458,10 +584,10 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : GTT
 
 #pragma unroll
             for (int j = 0; j < TPS; ++j) {
-                int po[2];
+                int po[NF];
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const int r = wn * 2 + ni;
+                for (int ni = 0; ni < NF; ++ni) {
+                    const int r = wn * NF + ni;
                     if (MODE == CONV_C3 || MODE == CONV_C7) po[ni] = (r + stage) * HC + j;
                     else if (MODE == CONV_DN) po[ni] = (2 * r + stage) * HC + (j == 1 ? 33 : (j >> 1));
                     else if (MODE == CONV_UP) {
@@ -472,10 +598,10 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : GTT
                 }
 #pragma unroll
                 for (int kc = 0; kc < KCH; ++kc) {
-                    bf16x8 wh[MF], wl[MF], xh[2], xl[2];
+                    bf16x8 wh[MF], wl[MF], xh[NF], xl[NF];
 #if GTTS_EXP == 2
                     for (int mi = 0; mi < MF; ++mi) { wh[mi] = __builtin_bit_cast(bf16x8, wregs[0]); wl[mi] = wh[mi]; }
-                    for (int ni = 0; ni < 2; ++ni) { xh[ni] = __builtin_bit_cast(bf16x8, wregs[1]); xl[ni] = xh[ni]; }
+                    for (int ni = 0; ni < NF; ++ni) { xh[ni] = __builtin_bit_cast(bf16x8, wregs[1]); xl[ni] = xh[ni]; }
 #else
 #pragma unroll
                     for (int mi = 0; mi < MF; ++mi) {
@@ -484,7 +610,7 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : GTT
                         if (NSPLIT > 1) wl[mi] = *reinterpret_cast<const bf16x8 *>(&s_wc[wi + TPS * NKG * MT]);
                     }
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
+                    for (int ni = 0; ni < NF; ++ni) {
                         int xi = (kc * 2 + kg_l) * NPIX + po[ni] + l31;
                         xh[ni] = *reinterpret_cast<const bf16x8 *>(&s_xh[xi]);
                         if (NSPLIT > 1) xl[ni] = *reinterpret_cast<const bf16x8 *>(&s_xl[xi]);
@@ -494,7 +620,7 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : GTT
 #pragma unroll
                     for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
-                        for (int ni = 0; ni < 2; ++ni) {      // consume the fragments with a handful of VALU ops
+                        for (int ni = 0; ni < NF; ++ni) {      // consume the fragments with a handful of VALU ops
                             const u32x4 p = __builtin_bit_cast(u32x4, wh[mi]) ^ __builtin_bit_cast(u32x4, xh[ni]);
                             u32x4 q = p;
                             if (NSPLIT > 1) q = __builtin_bit_cast(u32x4, wl[mi]) ^ __builtin_bit_cast(u32x4, xl[ni]);
@@ -504,7 +630,7 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : GTT
 #pragma unroll
                     for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
-                        for (int ni = 0; ni < 2; ++ni) {
+                        for (int ni = 0; ni < NF; ++ni) {
                             if (NSPLIT > 1) {
                                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[mi], xh[ni], acc[mi][ni], 0, 0, 0);
                                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[mi], xl[ni], acc[mi][ni], 0, 0, 0);
@@ -543,8 +669,8 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : GTT
         out_bytes);
     const int ch0 = __builtin_amdgcn_readfirstlane(cot * MT + m0);     // first channel of this wave's fragments
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int r = wn * 2 + ni;
+    for (int ni = 0; ni < NF; ++ni) {
+        const int r = wn * NF + ni;
         int oy = y0 + r, ox = x0 + l31;
         if (MODE == CONV_UP) { oy = 2 * oy + ph_y; ox = 2 * ox + ph_x; }
         const bool pix_ok = oy < a.Hout && ox < a.Wout;
@@ -615,18 +741,17 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : GTT
         if (tid < gpw) {
             const int g = (cot * MT) / gs + tid;       // global group index
             if (g < a.groups) {
+                // this group's octets inside the tile (gs is a multiple of 8; a group wider than the tile covers all of it):
+                // octet o belongs to fragment o / 4 = (wave row wmm, mi) and was summed by the WN waves of that row
+                const int noct = (gs < MT ? gs : MT) >> 3, o0 = tid * noct;
                 float s1 = 0.f, s2 = 0.f;
-                for (int w = 0; w < 4; ++w) {
-                    const int wmm = w / WN;
-                    for (int mi = 0; mi < MF; ++mi) {
-                        const int cbase = cot * MT + (wmm * MF + mi) * 32;      // first channel of fragment
-                        for (int q = 0; q < 4; ++q) {
-                            const int gq = (cbase + q * 8) / gs;
-                            if (gq == g) {
-                                s1 += s_red[((w * MF + mi) * 4 + q) * 2 + 0];
-                                s2 += s_red[((w * MF + mi) * 4 + q) * 2 + 1];
-                            }
-                        }
+                for (int o = o0; o < o0 + noct; ++o) {
+                    const int f = o >> 2, q = o & 3, wmm = f / MF, mi = f - wmm * MF;
+#pragma unroll
+                    for (int wc = 0; wc < WN; ++wc) {
+                        const int w = wmm * WN + wc;
+                        s1 += s_red[((w * MF + mi) * 4 + q) * 2 + 0];
+                        s2 += s_red[((w * MF + mi) * 4 + q) * 2 + 1];
                     }
                 }
                 float *p = a.partials + (((size_t)b * a.nparts + tile) * a.groups + g) * 2;
@@ -702,9 +827,9 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : GTT
 }
 
 
-template <int MODE, int WM, int WN, int MF, int KCH, int PRO, int EPI, int NSPLIT, int FULLC, typename AT = float>
+template <int MODE, int WM, int WN, int MF, int KCH, int PRO, int EPI, int NSPLIT, int FULLC, typename AT = float, int NF = 2, int PRIV = 0>
 static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
-    using C = ConvCfg<MODE, WM, WN, MF, KCH>;
+    using C = ConvCfg<MODE, WM, WN, MF, KCH, NF>;
     ConvArgs a = a_in;
     a.nchunk = (a.cin + 16 * KCH - 1) / (16 * KCH);
     const int th = (MODE == CONV_UP) ? a.Hin : a.Hout;   // tile space: input resolution for UP
@@ -718,9 +843,11 @@ static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
     const size_t lim = (size_t)1 << 31;
     const size_t in_c = (size_t)(PRO == PRO_IGLU ? 2 * a.cin : std::max(a.c0, a.c1));
     if (in_c * a.Hin * a.Win * sizeof(AT) >= lim || (size_t)a.cout * a.Hout * a.Wout * sizeof(AT) >= lim) return hipErrorInvalidValue;
-    size_t smem = conv_smem_bytes(C::NPIX, C::NKG, C::WBLK16, a.cin, PRO, C::MT) +
+    constexpr int WLDS16 = PRIV ? 4 * NSPLIT * C::TPS * C::NKG * MF * 32 : C::WBLK16;
+    size_t smem = conv_smem_bytes(C::NPIX, C::NKG, WLDS16, a.cin, PRO, C::MT) +
                   (ConvWdma<MODE, WM, FULLC>::on ? (size_t)C::WBLK16 * 16 : 0) +
                   (ConvAdbuf<MODE, WM, FULLC>::on ? (size_t)C::NPIX * C::NKG * 16 * 2 : 0);
+    if (smem < (size_t)GTTS_LDS_MIN) smem = (size_t)GTTS_LDS_MIN;
     // hipFuncSetAttribute is per device: remember the largest size set on each device (atomics: launches may come
     // from several host threads; setting the attribute twice is harmless)
     static std::atomic<size_t> attr_set[64];
@@ -728,12 +855,12 @@ static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (smem > attr_set[dev].load(std::memory_order_relaxed)) {
         hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&conv_mfma_kernel<MODE, WM, WN, MF, KCH, PRO, EPI, NSPLIT, FULLC, AT>),
+            reinterpret_cast<const void *>(&conv_mfma_kernel<MODE, WM, WN, MF, KCH, PRO, EPI, NSPLIT, FULLC, AT, NF, PRIV>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr_set[dev].store(smem, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, MF, KCH, PRO, EPI, NSPLIT, FULLC, AT>), grid, dim3(256), smem, st, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, MF, KCH, PRO, EPI, NSPLIT, FULLC, AT, NF, PRIV>), grid, dim3(256), smem, st, a);
     return hipGetLastError();
 }
 
@@ -759,6 +886,14 @@ static hipError_t launch_prec(const ConvArgs &a, hipStream_t st) {
             if constexpr (ragged_ok) return launch_cfg<MODE, WM, WN, MF, 1, PRO, EPI, 1, 0, __bf16>(a, st);
         }
         return hipErrorInvalidValue;
+    }
+    if constexpr (GTTS_PRIV && MODE == CONV_C3 && PRO != PRO_IGLU) {
+        // bf16x3 3x3 convolutions on whole chunks: private weight slices (same workgroup tiles, waves re-arranged to
+        // 32 channels x 4 rows each): 128 x (4 x 32) as 4 x 1 waves, 64 x (8 x 32) as 2 x 2 waves
+        if (fullc && a.nsplit > 1) {
+            if constexpr (WM == 2) return launch_cfg<MODE, 4, 1, 1, 1, PRO, EPI, 2, 1, float, 4, 1>(a, st);
+            else return launch_cfg<MODE, 2, 2, 1, 1, PRO, EPI, 2, 1, float, 4, 1>(a, st);
+        }
     }
     if (fullc)
         return a.nsplit > 1 ? launch_cfg<MODE, WM, WN, MF, 1, PRO, EPI, 2, 1>(a, st)
