@@ -9,7 +9,7 @@ SOURCES = ["plan.hip", "conv_mfma.hip", "attn.hip", "misc.hip", "pack.hip", "mas
 HEADERS = ["common.h", "kernels.h", "conv1d.h", os.path.join("..", "..", "include", "gradtts_abi.h")]
 # The SLP vectoriser packs the GroupNorm / Mish / split arithmetic of the conv prologue into v_pk_*_f32.  Beside MFMAs a
 # packed f32 op costs more issue time than the two scalar ops it replaces (MI355X guide; measured here: -1.6 % per U-Net call).
-PER_FILE_FLAGS = {"conv_mfma.hip": ["-fno-slp-vectorize"]}
+PER_FILE_FLAGS = {"conv_mfma.hip": ["-fno-slp-vectorize"]}      # (attn.hip: measured the other way, 185 vs 173 us -- it is VALU-bound and profits from the packing)
 LIB = os.path.join(HERE, os.environ.get("GTTS_LIB_NAME", "libgradtts_gfx950.so"))
 
 
@@ -33,7 +33,8 @@ def build(force=False, verbose=False):
         obj = os.path.join(bdir, src.replace(".hip", ".o"))
         objs.append(obj)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-        cmd += PER_FILE_FLAGS.get(src, [])
+        if src not in os.environ.get("GTTS_NO_PERFILE", "").split(","):      # A/B builds
+            cmd += PER_FILE_FLAGS.get(src, [])
         cmd += os.environ.get("GTTS_EXTRA_FLAGS", "").split()
         cmd += ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:

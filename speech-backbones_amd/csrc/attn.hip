@@ -152,36 +152,61 @@ __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
 
         // ---- online softmax over this wave's 64 pixels: lane (l31, kgl) owns channel d = l31 (k) / e = l31 (v)
         const int nbase = tile * 256 + wave * 64 + 4 * kgl;
+        const bool full = tile * 256 + 256 <= a.HW;          // workgroup-uniform: only the last tile of a sample is ragged
         float tmax = NEG_INF;
+        if (full) {
 #pragma unroll
-        for (int pf = 0; pf < 2; ++pf)
+            for (int pf = 0; pf < 2; ++pf)
 #pragma unroll
-            for (int rg = 0; rg < 16; ++rg) {
-                const int n = nbase + pf * 32 + (rg & 3) + 8 * (rg >> 2);
-                if (n < a.HW) tmax = fmaxf(tmax, acc[pf][0][rg]);
-            }
+                for (int rg = 0; rg < 16; ++rg) tmax = fmaxf(tmax, acc[pf][0][rg]);
+        } else {
+#pragma unroll
+            for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int n = nbase + pf * 32 + (rg & 3) + 8 * (rg >> 2);
+                    if (n < a.HW) tmax = fmaxf(tmax, acc[pf][0][rg]);
+                }
+        }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);
         const float alpha = (m_run == NEG_INF) ? 0.f : __expf(m_run - m_new);
         const float msub = (m_new == NEG_INF) ? 0.f : m_new;
+        // p = exp(k - m) as one fma + v_exp_f32 per element: exp2(k * log2(e) - m * log2(e))
+        constexpr float LOG2E = 1.44269504088896340736f;
+        const float ml2 = msub * LOG2E;
         float psum = 0.f;
+        if (full) {
 #pragma unroll
-        for (int pf = 0; pf < 2; ++pf)
+            for (int pf = 0; pf < 2; ++pf)
 #pragma unroll
-            for (int rg = 0; rg < 16; ++rg) {
-                const int n = nbase + pf * 32 + (rg & 3) + 8 * (rg >> 2);
-                const float p = (n < a.HW) ? __expf(acc[pf][0][rg] - msub) : 0.f;
-                acc[pf][0][rg] = p;
-                psum += p;
-            }
+                for (int rg = 0; rg < 16; ++rg) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[pf][0][rg], LOG2E, -ml2));
+                    acc[pf][0][rg] = p;
+                    psum += p;
+                }
+        } else {
+#pragma unroll
+            for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int n = nbase + pf * 32 + (rg & 3) + 8 * (rg >> 2);
+                    const float p = (n < a.HW) ? __builtin_amdgcn_exp2f(__builtin_fmaf(acc[pf][0][rg], LOG2E, -ml2)) : 0.f;
+                    acc[pf][0][rg] = p;
+                    psum += p;
+                }
+        }
         psum += __shfl_xor(psum, 32, 64);
         z_run = z_run * alpha + psum;
         m_run = m_new;
-        // ctx rows are d = (rg&3) + 8*(rg>>2) + 4*kgl: fetch that channel's rescale factor from lane d
+        // ctx rows are d = (rg&3) + 8*(rg>>2) + 4*kgl: fetch that channel's rescale factor from lane d.  Once the running
+        // maxima have settled every alpha is exactly 1 and the 16 cross-lane fetches + multiplies are skipped (wave-uniform)
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {
 #pragma unroll
-        for (int rg = 0; rg < 16; ++rg) {
-            const int d = (rg & 3) + 8 * (rg >> 2) + 4 * kgl;
-            ctx[rg] *= __shfl(alpha, d, 64);
+            for (int rg = 0; rg < 16; ++rg) {
+                const int d = (rg & 3) + 8 * (rg >> 2) + 4 * kgl;
+                ctx[rg] *= __shfl(alpha, d, 64);
+            }
         }
         // ctx[d][e] += sum_n p[d,n] v[e,n]: A = P (i = d), B = V (n = e); the k-slot (lane>>5, j) maps to the
         // same pixel in both operands because both come from the same C/D register layout.
@@ -247,14 +272,226 @@ __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ head-per-wave variant
+// C == 64 (attn_head_per_wave): a workgroup owns a slice of 64-pixel tiles for ALL FOUR heads, wave w = head w.  The x
+// tile (all 64 channels) is loaded, split into bf16 hi/lo and staged ONCE for the four heads (the per-head kernel above does
+// that four times, in four workgroups), and the k|v projection weights of a head -- 16 KB -- stay resident in that wave's own
+// LDS region for the whole workgroup, so nothing but the x image is shared: two workgroup barriers per tile (the per-head
+// kernel: four per 256-pixel tile, i.e. sixteen per 4 x 64 pixels).  Per wave and tile: 48 projection MFMAs + the online
+// softmax + 12 context MFMAs, exactly the unit of work of the per-head kernel; records go out per wave (= per head).
+template <int NSPLIT, typename AT>
+__global__ __launch_bounds__(256, 2) void attn_ctx64_kernel(const AttnCtxArgs a) {
+    constexpr int AB = (int)sizeof(AT);
+    constexpr int C = 64, NKGT = C / 8;                         // 8 channel groups of 8
+    constexpr bool lo_on = NSPLIT > 1;
+    __shared__ __attribute__((aligned(16))) u32x4 s_ah[NKGT * 64];          // [kg][pixel] hi
+    __shared__ __attribute__((aligned(16))) u32x4 s_al[NKGT * 64];          // [kg][pixel] lo
+    __shared__ __attribute__((aligned(16))) u32x4 s_w[4][1024];             // per wave: [stage 2][split 2][kg 4][64 rows]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave index as an SGPR: it selects channel offsets of buffer loads (a VGPR there costs a waterfall loop per load)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kgl = lane >> 5;
+    const int nsl = gridDim.x / a.B;
+    const int wg = xcd_slot(blockIdx.x, gridDim.x);
+    const int slice = wg % nsl, b = wg / nsl;
+    const int head = wave;
+    const int tile0 = slice * a.tps, tile1 = min(tile0 + a.tps, a.tiles);
+    const AT *xb = reinterpret_cast<const AT *>(a.x) + (size_t)b * C * a.HW;
+
+    // this head's packed projection weights: one contiguous 16 KB block, copied once
+    {
+        const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(a.wkv) + (size_t)head * 1024;
+        u32x4 wr[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wr[i] = wsrc[lane + 64 * i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s_w[wave][lane + 64 * i] = wr[i];
+    }
+
+    const unsigned long long xaddr = reinterpret_cast<unsigned long long>(xb);
+    const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xaddr);
+    const unsigned xhi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));
+    const int xbytes = C * a.HW * AB;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void *>(((unsigned long long)xhi << 32) | xlo), 0, __builtin_amdgcn_readfirstlane(xbytes), 0x00020000);
+    // staging items: thread -> (channel group kg = it * 4 + wave, pixel = lane); the channel offset is wave-uniform
+    float raw[2][8];
+    auto load = [&](int tile) {
+        const int n = tile * 64 + lane;
+        const int voff = n < a.HW ? n * AB : xbytes;               // beyond the sample: the bounds check returns 0
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = (it * 4 + wave) * 8 + i;
+                if constexpr (AB == 4) raw[it][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, voff, c * a.HW * 4, 0));
+                else raw[it][i] = __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsx, voff, c * a.HW * 2, 0) << 16);
+            }
+    };
+
+    const float NEG_INF = -__builtin_inff();
+    float m_run = NEG_INF, z_run = 0.f;
+    f32x16 ctx;          // (two accumulators -- two dependent chains of 6 context MFMAs instead of one of 12 -- measured: no change)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
+
+    load(tile0);
+    for (int tile = tile0; tile < tile1; ++tile) {
+        lds_barrier();                                  // every head is done with the previous tile's image (first pass: s_w is written)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            u32x4 hi, lo;
+            pack8_split(raw[it], hi, lo);
+            s_ah[(it * 4 + wave) * 64 + lane] = hi;
+            if (lo_on) s_al[(it * 4 + wave) * 64 + lane] = lo;
+        }
+        lds_barrier();
+        load(min(tile + 1, tile1 - 1));                 // unconditional prefetch (exact waitcnt; the last one is never used)
+
+        f32x16 acc[2][2];     // [pixel fragment][0: k_h, 1: v_h]; D layout: col = channel, rows = pixels
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
+            for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[pf][cf][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {                   // 16-channel k-steps
+            bf16x8 xh[2], xl[2], wh[2], wl[2];
+#pragma unroll
+            for (int pf = 0; pf < 2; ++pf) {
+                const int xi = (s * 2 + kgl) * 64 + pf * 32 + l31;
+                xh[pf] = *reinterpret_cast<const bf16x8 *>(&s_ah[xi]);
+                if (lo_on) xl[pf] = *reinterpret_cast<const bf16x8 *>(&s_al[xi]);
+            }
+#pragma unroll
+            for (int cf = 0; cf < 2; ++cf) {
+                const int wi = (s >> 1) * 512 + ((s & 1) * 2 + kgl) * 64 + cf * 32 + l31;
+                wh[cf] = *reinterpret_cast<const bf16x8 *>(&s_w[wave][wi]);
+                if (lo_on) wl[cf] = *reinterpret_cast<const bf16x8 *>(&s_w[wave][wi + 256]);
+            }
+#pragma unroll
+            for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
+                for (int cf = 0; cf < 2; ++cf) {
+                    if (lo_on) {
+                        acc[pf][cf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[pf], wh[cf], acc[pf][cf], 0, 0, 0);
+                        acc[pf][cf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[pf], wl[cf], acc[pf][cf], 0, 0, 0);
+                    }
+                    acc[pf][cf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[pf], wh[cf], acc[pf][cf], 0, 0, 0);
+                }
+        }
+
+        // ---- online softmax over the tile's 64 pixels: lane (l31, kgl) owns channel d = l31 (k) / e = l31 (v)
+        const int nbase = tile * 64 + 4 * kgl;
+        const bool full = tile * 64 + 64 <= a.HW;
+        float tmax = NEG_INF;
+        if (full) {
+#pragma unroll
+            for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) tmax = fmaxf(tmax, acc[pf][0][rg]);
+        } else {
+#pragma unroll
+            for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int n = nbase + pf * 32 + (rg & 3) + 8 * (rg >> 2);
+                    if (n < a.HW) tmax = fmaxf(tmax, acc[pf][0][rg]);
+                }
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = (m_run == NEG_INF) ? 0.f : __expf(m_run - m_new);
+        const float msub = (m_new == NEG_INF) ? 0.f : m_new;
+        constexpr float LOG2E = 1.44269504088896340736f;
+        const float ml2 = msub * LOG2E;
+        float psum = 0.f;
+        if (full) {
+#pragma unroll
+            for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[pf][0][rg], LOG2E, -ml2));
+                    acc[pf][0][rg] = p;
+                    psum += p;
+                }
+        } else {
+#pragma unroll
+            for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int n = nbase + pf * 32 + (rg & 3) + 8 * (rg >> 2);
+                    const float p = (n < a.HW) ? __builtin_amdgcn_exp2f(__builtin_fmaf(acc[pf][0][rg], LOG2E, -ml2)) : 0.f;
+                    acc[pf][0][rg] = p;
+                    psum += p;
+                }
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        z_run = z_run * alpha + psum;
+        m_run = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) {
+                const int d = (rg & 3) + 8 * (rg >> 2) + 4 * kgl;
+                ctx[rg] *= __shfl(alpha, d, 64);
+            }
+        }
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                float pv[8], vv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    pv[i] = acc[pf][0][hh * 8 + i];
+                    vv[i] = acc[pf][1][hh * 8 + i];
+                }
+                u32x4 ph, pl, vh, vl;
+                pack8_split(pv, ph, pl);
+                pack8_split(vv, vh, vl);
+                const bf16x8 Ph = *reinterpret_cast<bf16x8 *>(&ph), Pl = *reinterpret_cast<bf16x8 *>(&pl);
+                const bf16x8 Vh = *reinterpret_cast<bf16x8 *>(&vh), Vl = *reinterpret_cast<bf16x8 *>(&vl);
+                if (lo_on) {
+                    ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Pl, Vh, ctx, 0, 0, 0);
+                    ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ph, Vl, ctx, 0, 0, 0);
+                }
+                ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ph, Vh, ctx, 0, 0, 0);
+            }
+    }
+
+    // ---- one record per wave (= per head): m[32], Z[32], ctx[32][32] relative to m
+    float *rec = a.partials + ((((size_t)b * 4 + head) * a.nrec) + (size_t)slice) * ATTN_REC;
+    if (kgl == 0) {
+        rec[l31] = m_run;
+        rec[32 + l31] = z_run;
+    }
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+        const int d = (rg & 3) + 8 * (rg >> 2) + 4 * kgl;
+        rec[64 + d * 32 + l31] = ctx[rg];
+    }
+}
+
 hipError_t launch_attn_ctx(const void *x, const unsigned char *wkv, float *partials, int B, int C, int HW, int nsplit,
                            hipStream_t st, int act_bf16) {
-    AttnGeom g = attn_geom(HW);
+    AttnGeom g = attn_geom(HW, C);
     if ((size_t)C * HW * 4 >= ((size_t)1 << 31)) return hipErrorInvalidValue;     // 32-bit offsets in the buffer descriptor
     AttnCtxArgs a;
     a.x = x; a.wkv = wkv; a.partials = partials; a.C = C; a.HW = HW;
     a.nstage = (C + 16 * ATTN_KCH - 1) / (16 * ATTN_KCH);
     a.tiles = g.tiles; a.tps = g.tps; a.nrec = g.nrec; a.nsplit = nsplit; a.B = B;
+    if (attn_head_per_wave(C)) {
+        static_assert(ATTN_KCH == 2, "attn_ctx64_kernel indexes the packed k|v blocks as 32-channel stages");
+        const dim3 grid64(g.nslices * B);
+        if (act_bf16) {
+            if (nsplit > 1) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((attn_ctx64_kernel<1, __bf16>), grid64, dim3(256), 0, st, a);
+        } else if (nsplit > 1) hipLaunchKernelGGL((attn_ctx64_kernel<2, float>), grid64, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_ctx64_kernel<1, float>), grid64, dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
     const dim3 grid(g.nslices * 4 * B);
     if (act_bf16) {
         if (nsplit > 1) return hipErrorInvalidValue;

@@ -68,16 +68,25 @@ int conv_nparts(int mode, int cout, int Hout, int Wout);
 constexpr int ATTN_KCH = 2;                 // 16-channel chunks per LDS stage of the k/v projection
 constexpr int ATTN_REC = 32 + 32 + 32 * 32; // floats per partial record: m[32], Z[32], ctx[32][32]
 struct AttnGeom {
-    int tiles;          // 256-pixel tiles per sample
+    int tiles;          // pixel tiles per sample (256 pixels; 64 in the head-per-wave kernel)
     int tps;            // tiles per slice (one workgroup walks a slice)
     int nslices;
-    int nrec;           // partial records per (sample, head) = nslices (a workgroup merges its four waves)
+    int nrec;           // partial records per (sample, head) = nslices
 };
-static inline AttnGeom attn_geom(int HW) {
+// C == 64 (level-0 and the last up-level attention, half of all attention work) runs the head-per-wave kernel: a workgroup
+// owns a slice of 64-pixel tiles for ALL FOUR heads (wave = head), so x is loaded and split once instead of four times.
+static inline bool attn_head_per_wave(int C) { return C == 64; }
+static inline AttnGeom attn_geom(int HW, int C) {
     AttnGeom g;
-    g.tiles = (HW + 255) / 256;
-    int t = g.tiles / 16;
-    g.tps = t < 1 ? 1 : (t > 16 ? 16 : t);
+    if (attn_head_per_wave(C)) {
+        g.tiles = (HW + 63) / 64;
+        int t = g.tiles / 64;
+        g.tps = t < 1 ? 1 : (t > 64 ? 64 : t);
+    } else {
+        g.tiles = (HW + 255) / 256;
+        int t = g.tiles / 16;
+        g.tps = t < 1 ? 1 : (t > 16 ? 16 : t);
+    }
     g.nslices = (g.tiles + g.tps - 1) / g.tps;
     g.nrec = g.nslices;
     return g;

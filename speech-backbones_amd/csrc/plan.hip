@@ -263,7 +263,7 @@ static int add_attn(gtts_plan *p, const std::string &name, int src, int C, int l
     add_param(p, pre + "fn.fn.to_qkv.weight", {384, C, 1, 1}, 5, C, 384);
     add_param(p, pre + "fn.fn.to_out.weight", {C, 128, 1, 1}, 0);
     add_param(p, pre + "fn.fn.to_out.bias", {C}, 0);
-    const int apart = add_tensor(p, name + ".apart", TK_APART, 0, lvl);
+    const int apart = add_tensor(p, name + ".apart", TK_APART, C, lvl);
     const int ctxn = add_tensor(p, name + ".ctx", TK_PERB, 4096, 0);
     const int wpk = add_tensor(p, name + ".wfold", TK_BYTES_PERB, 0, 0);
     p->tensors[wpk].bytes = align_up(conv_packed_bytes(CONV_P1, C, C), 256);
@@ -274,7 +274,7 @@ static int add_attn(gtts_plan *p, const std::string &name, int src, int C, int l
     a.src0 = src; a.C = C; a.lvl_in = lvl; a.wkv_off = qkv.off; a.apart = apart;
     p->ops.push_back(a);
     Op m = blank_op(OP_AMERGE, name + ".merge");
-    m.apart = apart; m.ctxn = ctxn; m.lvl_in = lvl;
+    m.apart = apart; m.ctxn = ctxn; m.lvl_in = lvl; m.C = C;
     p->ops.push_back(m);
     Op f = blank_op(OP_AFOLD, name + ".fold");
     f.ctxn = ctxn; f.C = C; f.wq_off = qkv.off2; f.wout_off = poff(p, pre + "fn.fn.to_out.weight");
@@ -638,7 +638,7 @@ static size_t tensor_bytes(const gtts_plan *p, const Tensor &t, int B, int T, in
         case TK_ACT: return (size_t)B * t.C * H * W * (p->cfg.precision == GTTS_PREC_BF16_STORE ? 2 : 4);
         case TK_PERB: return (size_t)B * t.C * 4;
         case TK_PART: return (size_t)B * conv_nparts(t.mode, t.cout, (int)H, (int)W) * t.C * 2 * 4;
-        case TK_APART: return (size_t)B * 4 * attn_geom((int)(H * W)).nrec * ATTN_REC * 4;
+        case TK_APART: return (size_t)B * 4 * attn_geom((int)(H * W), t.C).nrec * ATTN_REC * 4;
         case TK_BYTES_PERB: return (size_t)B * t.bytes;
         case TK_ROWS: return ((size_t)rows * p->tmlp.tb_stride + 4096) * 4;   // + the sampler's step times
     }
@@ -860,7 +860,7 @@ static int run_ops(const RunCtx &c) {
                 const int HW = (F >> o.lvl_in) * (c.T >> o.lvl_in);
                 hipError_t e = hipSuccess;
                 for (int rep = 0; rep < ((skip_op_mask() & 8) ? 2 : 1); ++rep)      // bit 3: launch twice (idempotent)
-                e = launch_attn_merge(tptr(c, o.apart), tptr(c, o.ctxn), c.B, attn_geom(HW).nrec, c.st);
+                e = launch_attn_merge(tptr(c, o.apart), tptr(c, o.ctxn), c.B, attn_geom(HW, o.C).nrec, c.st);
                 if (e != hipSuccess) return fail(GTTS_E_HIP, "attn_merge %s: %s", o.label.c_str(), hipGetErrorString(e));
                 break;
             }
