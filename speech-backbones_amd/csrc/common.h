@@ -132,6 +132,7 @@ struct ConvArgs {
     float *gn_sc, *gn_sh;   // [B][cout]
     float gn_count;         // elements per group = (cout / groups) * Hout * Wout
     int tiles_x, tiles_y;
+    int stat_rows;          // EPI_STATS: partial slots per (row pair, column block) instead of per tile (set by launch_cfg)
 };
 
 // geometry of one conv configuration (compile-time in the kernel, mirrored on the host)
@@ -166,5 +167,7 @@ static inline size_t conv_packed_bytes(int mode, int cin, int cout) {
 }
 
 hipError_t launch_conv(int mode, const ConvArgs &a, hipStream_t st);
+bool conv_small_tiles(int mode, int cout, int Hout, int Wout, int B);   // half-height tiles for launches smaller than the chip
+bool conv_rowpair_stats(int mode, int cout, int Hout, int Wout);        // GroupNorm partial slots per row pair (batch-size independent)
 
 }  // namespace gtts

@@ -71,6 +71,12 @@
 #ifndef GTTS_PRIV
 #define GTTS_PRIV 0
 #endif
+// launches with fewer workgroups than this use half-height 3x3 tiles (conv_small_tiles).  Measured: 256 also catches the
+// 5-utterance sub-batches of the B = 16 sampler (200 workgroups) and costs 1 % there; 128 and 192 keep all of the B = 1 gain
+// (1.73 -> 1.57 ms per U-Net call) at no cost for B = 16.
+#ifndef GTTS_SMALL_WGS
+#define GTTS_SMALL_WGS 128
+#endif
 #ifndef GTTS_PRIV_WAVES
 #define GTTS_PRIV_WAVES 3
 #endif
@@ -738,23 +744,32 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
         if (tr_on) tr_e[2] = __builtin_amdgcn_s_memtime();
 #endif
         const int gpw = MT / gs > 0 ? MT / gs : 1;     // groups covered by this workgroup
-        if (tid < gpw) {
-            const int g = (cot * MT) / gs + tid;       // global group index
-            if (g < a.groups) {
+        // Partial slots: one per (tile, group) -- or, for layers that small launches tile with half-height tiles
+        // (a.stat_rows), one per (ROW PAIR, 32-column block, group): a wave row covers exactly one row pair in either tiling,
+        // its wave-level sums are the same numbers in the same order, so the statistics (and with them every output) are
+        // bit-identical whatever the batch size picked.  All slots of a workgroup are written by wave 0 (gpw * WN <= 64).
+        const int nsl = a.stat_rows ? WN : 1;
+        if (tid < gpw * nsl) {
+            const int gl = a.stat_rows ? tid % gpw : tid, wsel = a.stat_rows ? tid / gpw : -1;
+            const int g = (cot * MT) / gs + gl;        // global group index
+            const int prow = ty * WN + wsel;           // row pair of this wave row (NF == 2)
+            if (g < a.groups && (wsel < 0 || 2 * prow < a.Hout)) {
                 // this group's octets inside the tile (gs is a multiple of 8; a group wider than the tile covers all of it):
                 // octet o belongs to fragment o / 4 = (wave row wmm, mi) and was summed by the WN waves of that row
-                const int noct = (gs < MT ? gs : MT) >> 3, o0 = tid * noct;
+                const int noct = (gs < MT ? gs : MT) >> 3, o0 = gl * noct;
                 float s1 = 0.f, s2 = 0.f;
                 for (int o = o0; o < o0 + noct; ++o) {
                     const int f = o >> 2, q = o & 3, wmm = f / MF, mi = f - wmm * MF;
 #pragma unroll
                     for (int wc = 0; wc < WN; ++wc) {
+                        if (wsel >= 0 && wc != wsel) continue;
                         const int w = wmm * WN + wc;
                         s1 += s_red[((w * MF + mi) * 4 + q) * 2 + 0];
                         s2 += s_red[((w * MF + mi) * 4 + q) * 2 + 1];
                     }
                 }
-                float *p = a.partials + (((size_t)b * a.nparts + tile) * a.groups + g) * 2;
+                const int slot = a.stat_rows ? prow * a.tiles_x + tx : tile;
+                float *p = a.partials + (((size_t)b * a.nparts + slot) * a.groups + g) * 2;
                 if (a.ticket != nullptr) {
                     // write-through (sc1) stores: visible device-wide once vmcnt has drained, WITHOUT a release fence --
                     // an agent-scope release is buffer_wbl2, which writes back every dirty line of this XCD's L2 (all the
@@ -779,9 +794,32 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
             old = __builtin_amdgcn_readfirstlane(old);
             const unsigned total = (unsigned)(a.tiles_x * a.tiles_y * ncot);
             if (old == total - 1) {
-                const int g = lane >> 3, sub = lane & 7;          // 8 lanes per group, 8 groups
+                // This tail is serial (the last workgroup of the last sample runs it alone), so it is organised for few
+                // dependent memory round trips: 16 lanes walk the slots of a PAIR of groups, two 8-byte sc1 loads per slot
+                // and eight slots in flight per lane; then 8 lanes per group finish.  Fixed order: deterministic.
+                const int g = lane >> 3, sub = lane & 7;          // final owner: 8 lanes per group, 8 groups
                 double s1 = 0.0, s2 = 0.0;
-                if (g < a.groups) {
+                if (a.groups == 8) {
+                    const int gp = lane >> 4, s16 = lane & 15;    // group pair (2 gp, 2 gp + 1), slot residue
+                    double t1[2] = {0.0, 0.0}, t2[2] = {0.0, 0.0};
+                    const float *pp = a.partials + ((size_t)b * a.nparts * 8 + 2 * gp) * 2;
+#pragma unroll 8
+                    for (int i = s16; i < a.nparts; i += 16) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const unsigned long long u = __hip_atomic_load(
+                                reinterpret_cast<const unsigned long long *>(pp + ((size_t)i * 8 + h) * 2), __ATOMIC_RELAXED,
+                                __HIP_MEMORY_SCOPE_AGENT);
+                            t1[h] += (double)__builtin_bit_cast(float, (unsigned)u);
+                            t2[h] += (double)__builtin_bit_cast(float, (unsigned)(u >> 32));
+                        }
+                    }
+                    // lanes (gp, s16) -> group 2 gp + (s16 >> 3) keeps its own half and takes the partner's (s16 ^ 8)
+                    const int hsel = s16 >> 3;
+                    const double give1 = hsel ? t1[0] : t1[1], give2 = hsel ? t2[0] : t2[1];
+                    s1 = (hsel ? t1[1] : t1[0]) + __shfl_xor(give1, 8, 64);
+                    s2 = (hsel ? t2[1] : t2[0]) + __shfl_xor(give2, 8, 64);
+                } else if (g < a.groups) {
                     const float *pp = a.partials + ((size_t)b * a.nparts * a.groups + g) * 2;
                     // (sum, sum of squares) pairs as one 8-byte sc1 load each, eight in flight per lane
 #pragma unroll 8
@@ -837,6 +875,8 @@ static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
     a.tiles_x = (tw + C::TC - 1) / C::TC;
     a.tiles_y = (th + C::TR - 1) / C::TR;
     const int ncot = (a.cout + C::MT - 1) / C::MT;
+    a.stat_rows = (EPI == EPI_STATS && conv_rowpair_stats(MODE, a.cout, a.Hout, a.Wout)) ? 1 : 0;
+    if (a.stat_rows && NF != 2) return hipErrorInvalidValue;       // a wave row must be one row pair (not the PRIV experiment)
     dim3 grid(a.tiles_x * a.tiles_y * ncot * (MODE == CONV_UP ? 4 : 1) * a.B);
     if (a.cout % C::MT != 0) return hipErrorInvalidValue;   // epilogue assumes whole output-channel tiles
     // buffer descriptors address one sample's tensor with 32-bit byte offsets
@@ -864,8 +904,22 @@ static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
     return hipGetLastError();
 }
 
-// number of GroupNorm partial slots per sample that EPI_STATS writes for this layer
+// Small launches (B = 1, what Grad-TTS/inference.py runs): a 3x3 layer whose regular tiling yields fewer than GTTS_SMALL_WGS
+// workgroups (half the CUs) is tiled with half-height tiles (128 x (2 x 32) / 64 x (4 x 32)): twice the workgroups, each half as long.
+// The kernel is latency-bound in that regime (one workgroup per CU, one wave per SIMD), so the time roughly halves.
+bool conv_small_tiles(int mode, int cout, int Hout, int Wout, int B) {
+    if (mode != CONV_C3 || B <= 0) return false;
+    ConvGeom g = conv_geom(mode, 64, cout);
+    const long wgs = (long)B * ((Wout + 31) / 32) * ((Hout + g.TR - 1) / g.TR) * ((cout + g.MT - 1) / g.MT);
+    return wgs < GTTS_SMALL_WGS;
+}
+// Layers that a small launch would tile with half-height tiles keep their GroupNorm partial sums per row pair (see the
+// kernel's statistics epilogue): a property of the layer geometry, NOT of the batch size, so that results do not depend on
+// how utterances are batched.
+bool conv_rowpair_stats(int mode, int cout, int Hout, int Wout) { return conv_small_tiles(mode, cout, Hout, Wout, 1); }
+// GroupNorm partial slots per sample that EPI_STATS writes for this layer
 int conv_nparts(int mode, int cout, int Hout, int Wout) {
+    if (conv_rowpair_stats(mode, cout, Hout, Wout)) return ((Wout + 31) / 32) * ((Hout + 1) / 2);
     ConvGeom g = conv_geom(mode, 64, cout);
     return ((Wout + 31) / 32) * ((Hout + g.TR - 1) / g.TR);
 }
@@ -876,6 +930,13 @@ int conv_nparts(int mode, int cout, int Hout, int Wout) {
 template <int MODE, int WM, int WN, int MF, int PRO, int EPI>
 static hipError_t launch_prec(const ConvArgs &a, hipStream_t st) {
     const bool fullc = a.cin % 16 == 0 && (a.c1 == 0 || a.c0 % 16 == 0);
+    if constexpr (MODE == CONV_C3 && PRO != PRO_IGLU) {
+        // half-height tiles for small launches (conv_small_tiles): same cout tile, waves re-arranged to 32 channels x 2 rows
+        if (fullc && !a.act_bf16 && a.nsplit > 1 && conv_small_tiles(MODE, a.cout, a.Hout, a.Wout, a.B)) {
+            if constexpr (WM == 2) return launch_cfg<MODE, 4, 1, 1, 1, PRO, EPI, 2, 1, float, 2, 0>(a, st);
+            else return launch_cfg<MODE, 2, 2, 1, 1, PRO, EPI, 2, 1, float, 2, 0>(a, st);
+        }
+    }
     // ragged channel counts only occur on first layers (stacked input, 1-channel reference): PRO_MASK variants
     constexpr bool ragged_ok = PRO == PRO_MASK && (MODE == CONV_C3 || MODE == CONV_P1);
     if (a.act_bf16) {

@@ -62,7 +62,10 @@ hipError_t launch_prep_vc(const float *mean, const float *x, const float *cond, 
                           hipStream_t st);
 
 // ---- conv_mfma.hip
+// GroupNorm partial slots per sample written by EPI_STATS for this layer (batch-size independent)
 int conv_nparts(int mode, int cout, int Hout, int Wout);
+bool conv_rowpair_stats(int mode, int cout, int Hout, int Wout);
+bool conv_small_tiles(int mode, int cout, int Hout, int Wout, int B);
 
 // ---- attn.hip  (LinearAttention, diffusion.py:82-100, folded: see attn.hip header)
 constexpr int ATTN_KCH = 2;                 // 16-channel chunks per LDS stage of the k/v projection
