@@ -277,6 +277,17 @@ int gtts_conv3x3_masked(const float *x, const float *mask, const void *packed, c
 int gtts_conv3x3_wgrad(const float *x, const float *mask, const float *dy, float *dw, float *db, int B, int cin, int cout, int H,
                        int W, gtts_stream_t stream);
 
+/* Block's GroupNorm + Mish + mask for training (Grad-TTS/model/diffusion.py:53-58,13-15): out = Mish(GroupNorm(y)) * mask.
+ * y, out [B,C,H,W]; gamma, beta [C]; mask [B,W] (columns).  stats [B][groups][2] = (mean, 1/sqrt(var + eps)) is written by the
+ * forward call and read by the backward call, which overwrites dy [B,C,H,W], dgamma [C], dbeta [C];
+ * scratch: gtts_gn_mish_scratch_bytes(B, C) bytes of device memory. */
+int gtts_gn_mish_forward(const float *y, const float *gamma, const float *beta, const float *mask, float *out, float *stats,
+                         int B, int C, int H, int W, int groups, float eps, gtts_stream_t stream);
+size_t gtts_gn_mish_scratch_bytes(int B, int C);
+int gtts_gn_mish_backward(const float *dout, const float *y, const float *gamma, const float *beta, const float *mask,
+                          const float *stats, float *dy, float *dgamma, float *dbeta, void *scratch, int B, int C, int H, int W,
+                          int groups, gtts_stream_t stream);
+
 /* ---- debugging / tests: named intermediates of the last estimator call (keep_intermediates plans) ----- */
 int gtts_plan_num_tensors(const gtts_plan *plan);
 /* offset is in bytes into the workspace for the given (B,T); dims = {B,C,H,W}. */

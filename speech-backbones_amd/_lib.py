@@ -89,6 +89,10 @@ def lib():
         L.gtts_conv3x3_pack.argtypes = [vp, vp, i, i, i, vp]
         L.gtts_conv3x3_masked.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, vp]
         L.gtts_conv3x3_wgrad.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, vp]
+        L.gtts_gn_mish_forward.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, f, vp]
+        L.gtts_gn_mish_scratch_bytes.argtypes = [i, i]
+        L.gtts_gn_mish_scratch_bytes.restype = sz
+        L.gtts_gn_mish_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, vp]
         L.gtts_enc_create.argtypes = [ctypes.POINTER(EncCfg), ctypes.POINTER(vp)]
         L.gtts_enc_destroy.argtypes = [vp]
         L.gtts_enc_destroy.restype = None
@@ -826,6 +830,33 @@ def conv3x3_wgrad(x, mask_cols, dy):
         _check(lib().gtts_conv3x3_wgrad(_ptr(x), _ptr(mask_cols), _ptr(dy), _ptr(dw), _ptr(db), B, cin, cout, H, W, _stream()),
                "gtts_conv3x3_wgrad")
     return dw, db
+
+
+def gn_mish_forward(y, gamma, beta, mask_cols, groups, eps):
+    """(Mish(GroupNorm(y)) * mask, stats [B, groups, 2]) -- Block.forward after the convolution (diffusion.py:53-58)."""
+    y, gamma, beta, mask_cols = _f32c(y, "y"), _f32c(gamma, "gamma"), _f32c(beta, "beta"), _f32c(mask_cols, "mask")
+    B, C, H, W = y.shape
+    out = torch.empty_like(y)
+    stats = torch.empty((B, groups, 2), dtype=torch.float32, device=y.device)
+    with torch.cuda.device(y.device):
+        _check(lib().gtts_gn_mish_forward(_ptr(y), _ptr(gamma), _ptr(beta), _ptr(mask_cols), _ptr(out), _ptr(stats), B, C, H, W,
+                                          int(groups), float(eps), _stream()), "gtts_gn_mish_forward")
+    return out, stats
+
+
+def gn_mish_backward(dout, y, gamma, beta, mask_cols, stats, groups):
+    """(dy, dgamma, dbeta) of gn_mish_forward."""
+    dout, y = _f32c(dout, "dout"), _f32c(y, "y")
+    B, C, H, W = y.shape
+    dy = torch.empty_like(y)
+    dg = torch.empty((C,), dtype=torch.float32, device=y.device)
+    db = torch.empty((C,), dtype=torch.float32, device=y.device)
+    scratch = torch.empty(int(lib().gtts_gn_mish_scratch_bytes(B, C)), dtype=torch.uint8, device=y.device)
+    with torch.cuda.device(y.device):
+        _check(lib().gtts_gn_mish_backward(_ptr(dout), _ptr(y), _ptr(_f32c(gamma, "gamma")), _ptr(_f32c(beta, "beta")),
+                                           _ptr(_f32c(mask_cols, "mask")), _ptr(stats), _ptr(dy), _ptr(dg), _ptr(db), _ptr(scratch),
+                                           B, C, H, W, int(groups), _stream()), "gtts_gn_mish_backward")
+    return dy, dg, db
 
 
 def diffusion_noising(x0, mu, z, mask, t, beta_min, beta_max):

@@ -3,8 +3,9 @@
 Training (Diffusion.compute_loss -> loss_t -> estimator with autograd, Grad-TTS/model/diffusion.py:281-294) needs gradients
 w.r.t. the same nn.Parameters.  On HIP tensors the 3x3 Block convolutions -- 84 % of the network's FLOPs, forward and
 backward -- run on the hand-written kernels of csrc/train.hip (forward and data gradient on the inference MFMA kernel,
-weight gradient as an MFMA reduction over pixels) through `MaskedConv3x3`, and the loss head through `ScoreLoss`; GroupNorm,
-Mish, attention and the small convolutions are PyTorch-ROCm differentiable ops (first stage).
+weight gradient as an MFMA reduction over pixels) through `MaskedConv3x3`, every Block's GroupNorm + Mish + mask (forward and
+backward fused, csrc/train_norm.hip) through `GnMishMask`, and the loss head through `ScoreLoss`; attention, the 1x1 / resampling
+convolutions and the small MLPs are PyTorch-ROCm differentiable ops.
 On CPU tensors (tests) everything is stock torch.
 """
 import math
@@ -37,6 +38,25 @@ class MaskedConv3x3(torch.autograd.Function):
         return dx, None, dw, db
 
 
+class GnMishMask(torch.autograd.Function):
+    """Mish(GroupNorm(y)) * mask (Block.forward, diffusion.py:53-58) with forward and backward on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, y, mask, gamma, beta, groups, eps):
+        be = backend()
+        cols = mask.reshape(mask.shape[0], mask.shape[-1])          # [B,1,1,W] -> [B,W]
+        out, stats = be.gn_mish_forward(y, gamma, beta, cols, groups, eps)
+        ctx.save_for_backward(y, cols, gamma, beta, stats)
+        ctx.groups = groups
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, cols, gamma, beta, stats = ctx.saved_tensors
+        dy, dg, db = backend().gn_mish_backward(dout.contiguous(), y, gamma, beta, cols, stats, ctx.groups)
+        return dy, None, dg, db, None, None
+
+
 class ScoreLoss(torch.autograd.Function):
     """sum((eps * sqrt(1 - e^{-cum}) + z)^2) / denom with the gradient produced in the same pass (diffusion.py:285-287)."""
 
@@ -67,6 +87,8 @@ def _conv_gn_mish(blk, v, m):
         y = MaskedConv3x3.apply(v.contiguous(), m, conv.weight, conv.bias)
     else:
         y = F.conv2d(v * m, conv.weight, conv.bias, padding=1)
+    if y.is_cuda and y.dtype == torch.float32:
+        return GnMishMask.apply(y.contiguous(), m, norm.weight, norm.bias, norm.num_groups, norm.eps)
     y = F.group_norm(y, norm.num_groups, norm.weight, norm.bias, norm.eps)
     return _mish(y) * m
 

@@ -54,6 +54,30 @@ def test_conv3x3_forward_dgrad_wgrad(S, dev, B, cin, cout, H, W):
     assert float((xg.grad.cpu() * (1 - mask)).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 80, 44), (3, 128, 40, 17), (1, 256, 20, 13), (2, 16, 5, 7)])
+def test_gn_mish_forward_backward(S, dev, B, C, H, W):
+    """Mish(GroupNorm_8(y)) * mask (Block.forward, diffusion.py:53-58) and all three gradients (dy, dgamma, dbeta) against torch
+    autograd on the CPU; ragged masks (the statistics include the masked frames), odd plane sizes."""
+    T = importlib.import_module("speech-backbones_amd.model._train_ops")
+    g = torch.Generator().manual_seed(C + W)
+    y = (2.0 * torch.randn(B, C, H, W, generator=g) + 0.3).requires_grad_(True)
+    gamma = (1.0 + 0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    lens = torch.tensor([W] + [max(1, W - 3 * (k + 1)) for k in range(B - 1)])
+    mask = O.sequence_mask(lens, W).float()[:, None, None, :]
+    dout = torch.randn(B, C, H, W, generator=g)
+    z = F.group_norm(y, 8, gamma, beta, 1e-5)
+    ref = z * torch.tanh(F.softplus(z)) * mask
+    ref.backward(dout)
+    yg, gg, bg = (t.detach().clone().to(dev).requires_grad_(True) for t in (y, gamma, beta))
+    out = T.GnMishMask.apply(yg, mask.to(dev), gg, bg, 8, 1e-5)
+    out.backward(dout.to(dev))
+    assert relerr(out.detach().cpu(), ref.detach()) <= 1e-5
+    assert relerr(yg.grad.cpu(), y.grad) <= REL
+    assert relerr(gg.grad.cpu(), gamma.grad) <= REL
+    assert relerr(bg.grad.cpu(), beta.grad) <= REL
+
+
 def test_noising_and_loss_kernels(S, dev):
     """forward_diffusion (diffusion.py:244-252) and the loss head of loss_t (:285-287) against the torch expressions."""
     g = torch.Generator().manual_seed(5)
