@@ -277,6 +277,12 @@ int gtts_conv3x3_masked(const float *x, const float *mask, const void *packed, c
 int gtts_conv3x3_wgrad(const float *x, const float *mask, const float *dy, float *dw, float *db, int B, int cin, int cout, int H,
                        int W, gtts_stream_t stream);
 
+/* The same weight / bias gradient as an LDS-tiled, deterministic reduction (no atomics): cin and cout multiples of 64;
+ * workspace: gtts_conv3x3_wgrad_workspace_bytes(...) bytes of device memory (per-slice partial tiles). */
+size_t gtts_conv3x3_wgrad_workspace_bytes(int B, int cin, int cout, int H, int W);
+int gtts_conv3x3_wgrad_tiled(const float *x, const float *mask, const float *dy, float *dw, float *db, void *workspace,
+                             size_t workspace_bytes, int B, int cin, int cout, int H, int W, gtts_stream_t stream);
+
 /* Block's GroupNorm + Mish + mask for training (Grad-TTS/model/diffusion.py:53-58,13-15): out = Mish(GroupNorm(y)) * mask.
  * y, out [B,C,H,W]; gamma, beta [C]; mask [B,W] (columns).  stats [B][groups][2] = (mean, 1/sqrt(var + eps)) is written by the
  * forward call and read by the backward call, which overwrites dy [B,C,H,W], dgamma [C], dbeta [C];

@@ -89,6 +89,9 @@ def lib():
         L.gtts_conv3x3_pack.argtypes = [vp, vp, i, i, i, vp]
         L.gtts_conv3x3_masked.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, vp]
         L.gtts_conv3x3_wgrad.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, vp]
+        L.gtts_conv3x3_wgrad_workspace_bytes.argtypes = [i, i, i, i, i]
+        L.gtts_conv3x3_wgrad_workspace_bytes.restype = sz
+        L.gtts_conv3x3_wgrad_tiled.argtypes = [vp, vp, vp, vp, vp, vp, sz, i, i, i, i, i, vp]
         L.gtts_gn_mish_forward.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, f, vp]
         L.gtts_gn_mish_scratch_bytes.argtypes = [i, i]
         L.gtts_gn_mish_scratch_bytes.restype = sz
@@ -827,8 +830,14 @@ def conv3x3_wgrad(x, mask_cols, dy):
     dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
     db = torch.empty((cout,), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _check(lib().gtts_conv3x3_wgrad(_ptr(x), _ptr(mask_cols), _ptr(dy), _ptr(dw), _ptr(db), B, cin, cout, H, W, _stream()),
-               "gtts_conv3x3_wgrad")
+        if cin % 64 == 0 and cout % 64 == 0:       # LDS-tiled deterministic reduction (train_wgrad.hip)
+            nws = int(lib().gtts_conv3x3_wgrad_workspace_bytes(B, cin, cout, H, W))
+            ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
+            _check(lib().gtts_conv3x3_wgrad_tiled(_ptr(x), _ptr(mask_cols), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), nws, B, cin, cout,
+                                                  H, W, _stream()), "gtts_conv3x3_wgrad_tiled")
+        else:
+            _check(lib().gtts_conv3x3_wgrad(_ptr(x), _ptr(mask_cols), _ptr(dy), _ptr(dw), _ptr(db), B, cin, cout, H, W, _stream()),
+                   "gtts_conv3x3_wgrad")
     return dw, db
 
 

@@ -72,8 +72,11 @@ class ScoreLoss(torch.autograd.Function):
         return g * dloss, None, None, None, None, None
 
 
+FORCE_TORCH = False      # measurement switch (bench.py train_step): route every op to stock PyTorch-ROCm kernels
+
+
 def _hip_conv_ok(v, conv):
-    return (v.is_cuda and v.dtype == torch.float32 and conv.kernel_size == (3, 3) and
+    return (not FORCE_TORCH and v.is_cuda and v.dtype == torch.float32 and conv.kernel_size == (3, 3) and
             backend().conv3x3_supported(conv.in_channels, conv.out_channels))
 
 
@@ -87,7 +90,7 @@ def _conv_gn_mish(blk, v, m):
         y = MaskedConv3x3.apply(v.contiguous(), m, conv.weight, conv.bias)
     else:
         y = F.conv2d(v * m, conv.weight, conv.bias, padding=1)
-    if y.is_cuda and y.dtype == torch.float32:
+    if y.is_cuda and y.dtype == torch.float32 and not FORCE_TORCH:
         return GnMishMask.apply(y.contiguous(), m, norm.weight, norm.bias, norm.num_groups, norm.eps)
     y = F.group_norm(y, norm.num_groups, norm.weight, norm.bias, norm.eps)
     return _mish(y) * m

@@ -30,7 +30,8 @@ def relerr(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-@pytest.mark.parametrize("B,cin,cout,H,W", [(2, 64, 64, 80, 64), (1, 128, 256, 20, 44), (3, 256, 128, 10, 17), (2, 512, 128, 20, 16)])
+@pytest.mark.parametrize("B,cin,cout,H,W", [(2, 64, 64, 80, 64), (1, 128, 256, 20, 44), (3, 256, 128, 10, 17), (2, 512, 128, 20, 16),
+                                            (1, 64, 64, 5, 37), (2, 64, 128, 7, 33)])
 def test_conv3x3_forward_dgrad_wgrad(S, dev, B, cin, cout, H, W):
     """y = conv3x3(x * mask) + b and its three gradients against torch autograd (CPU fp32); ragged masks, widths that are
     not multiples of the 16-pixel K-step or the 32-column tile."""
