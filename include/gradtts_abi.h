@@ -284,9 +284,11 @@ int gtts_conv3x3_wgrad_tiled(const float *x, const float *mask, const float *dy,
                              size_t workspace_bytes, int B, int cin, int cout, int H, int W, gtts_stream_t stream);
 
 /* Block's GroupNorm + Mish + mask for training (Grad-TTS/model/diffusion.py:53-58,13-15): out = Mish(GroupNorm(y)) * mask.
- * y, out [B,C,H,W]; gamma, beta [C]; mask [B,W] (columns).  stats [B][groups][2] = (mean, 1/sqrt(var + eps)) is written by the
- * forward call and read by the backward call, which overwrites dy [B,C,H,W], dgamma [C], dbeta [C];
+ * y, out [B,C,H,W]; gamma, beta [C]; mask [B,W] (columns).  stats: gtts_gn_mish_stats_floats(B, groups) floats, 8-byte aligned;
+ * its first [B][groups][2] = (mean, 1/sqrt(var + eps)) are written by the forward call (the rest is its reduction scratch) and
+ * read by the backward call, which overwrites dy [B,C,H,W], dgamma [C], dbeta [C];
  * scratch: gtts_gn_mish_scratch_bytes(B, C) bytes of device memory. */
+size_t gtts_gn_mish_stats_floats(int B, int groups);
 int gtts_gn_mish_forward(const float *y, const float *gamma, const float *beta, const float *mask, float *out, float *stats,
                          int B, int C, int H, int W, int groups, float eps, gtts_stream_t stream);
 size_t gtts_gn_mish_scratch_bytes(int B, int C);

@@ -93,6 +93,8 @@ def lib():
         L.gtts_conv3x3_wgrad_workspace_bytes.restype = sz
         L.gtts_conv3x3_wgrad_tiled.argtypes = [vp, vp, vp, vp, vp, vp, sz, i, i, i, i, i, vp]
         L.gtts_gn_mish_forward.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, f, vp]
+        L.gtts_gn_mish_stats_floats.argtypes = [i, i]
+        L.gtts_gn_mish_stats_floats.restype = sz
         L.gtts_gn_mish_scratch_bytes.argtypes = [i, i]
         L.gtts_gn_mish_scratch_bytes.restype = sz
         L.gtts_gn_mish_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, vp]
@@ -842,11 +844,11 @@ def conv3x3_wgrad(x, mask_cols, dy):
 
 
 def gn_mish_forward(y, gamma, beta, mask_cols, groups, eps):
-    """(Mish(GroupNorm(y)) * mask, stats [B, groups, 2]) -- Block.forward after the convolution (diffusion.py:53-58)."""
+    """(Mish(GroupNorm(y)) * mask, stats: (mean, rstd) pairs followed by reduction scratch) -- Block.forward after the convolution (diffusion.py:53-58)."""
     y, gamma, beta, mask_cols = _f32c(y, "y"), _f32c(gamma, "gamma"), _f32c(beta, "beta"), _f32c(mask_cols, "mask")
     B, C, H, W = y.shape
     out = torch.empty_like(y)
-    stats = torch.empty((B, groups, 2), dtype=torch.float32, device=y.device)
+    stats = torch.empty(int(lib().gtts_gn_mish_stats_floats(B, int(groups))), dtype=torch.float32, device=y.device)
     with torch.cuda.device(y.device):
         _check(lib().gtts_gn_mish_forward(_ptr(y), _ptr(gamma), _ptr(beta), _ptr(mask_cols), _ptr(out), _ptr(stats), B, C, H, W,
                                           int(groups), float(eps), _stream()), "gtts_gn_mish_forward")

@@ -38,14 +38,17 @@ __device__ __forceinline__ void block_sum2(double &a, double &b, double *s_a, do
     __syncthreads();
 }
 
-// grid (B * groups): mean and 1 / sqrt(var + eps) of one (sample, group): a contiguous run of (C / groups) * HW floats
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__ y, float *__restrict__ stats, size_t n, float eps) {
+// grid (B * groups, GN_SPLIT): partial (sum, sum of squares) of one slice of a (sample, group) region -- a contiguous run of
+// (C / groups) * HW floats -- as doubles; 128 regions alone would leave half of the chip idle
+constexpr int GN_SPLIT = 16;
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__ y, double *__restrict__ partial, size_t n) {
     __shared__ double s_a[256], s_b[256];
+    const size_t per = (n + GN_SPLIT - 1) / GN_SPLIT, i0 = blockIdx.y * per, i1 = i0 + per < n ? i0 + per : n;
     const float *p = y + (size_t)blockIdx.x * n;
     float s1 = 0.f, s2 = 0.f;
     double d1 = 0.0, d2 = 0.0;
     int k = 0;
-    for (size_t i = threadIdx.x; i < n; i += 256) {
+    for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
         const float v = p[i];
         s1 += v;
         s2 += v * v;
@@ -58,12 +61,24 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__
     d2 += (double)s2;
     block_sum2(d1, d2, s_a, s_b);
     if (threadIdx.x == 0) {
-        const double mean = d1 / (double)n;
-        double var = d2 / (double)n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        stats[2 * blockIdx.x] = (float)mean;
-        stats[2 * blockIdx.x + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        partial[2 * ((size_t)blockIdx.x * GN_SPLIT + blockIdx.y)] = d1;
+        partial[2 * ((size_t)blockIdx.x * GN_SPLIT + blockIdx.y) + 1] = d2;
     }
+}
+// one thread per (sample, group): mean and 1 / sqrt(var + eps) from the GN_SPLIT partials (fixed order)
+__global__ void gn_stats_finish_kernel(const double *__restrict__ partial, float *__restrict__ stats, int nbg, double inv_n, float eps) {
+    const int bg = blockIdx.x * 256 + threadIdx.x;
+    if (bg >= nbg) return;
+    double d1 = 0.0, d2 = 0.0;
+    for (int s = 0; s < GN_SPLIT; ++s) {
+        d1 += partial[2 * ((size_t)bg * GN_SPLIT + s)];
+        d2 += partial[2 * ((size_t)bg * GN_SPLIT + s) + 1];
+    }
+    const double mean = d1 * inv_n;
+    double var = d2 * inv_n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[2 * bg] = (float)mean;
+    stats[2 * bg + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
 // Mish and its derivative from one exponential: e = exp(z), n = e (e + 2), tanh(softplus(z)) = n / (n + 2),
@@ -211,11 +226,19 @@ extern "C" int gtts_gn_mish_forward(const float *y, const float *gamma, const fl
     if (!norm_shape_ok(B, C, H, W, groups)) return nfail(GTTS_E_SHAPE, "gtts_gn_mish_forward: bad shape B=%d C=%d H=%d W=%d groups=%d", B, C, H, W, groups);
     const int HW = H * W, cpg = C / groups;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(B * groups), dim3(256), 0, st, y, stats, (size_t)cpg * HW, eps);
+    double *partial = reinterpret_cast<double *>(stats + (size_t)B * groups * 2);      // behind the (mean, rstd) pairs (8-byte aligned)
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(B * groups, GN_SPLIT), dim3(256), 0, st, y, partial, (size_t)cpg * HW);
+    NCHK(hipGetLastError());
+    hipLaunchKernelGGL(gn_stats_finish_kernel, dim3((B * groups + 255) / 256), dim3(256), 0, st, partial, stats, B * groups,
+                       1.0 / ((double)cpg * HW), eps);
     NCHK(hipGetLastError());
     hipLaunchKernelGGL(gn_mish_fwd_kernel, dim3(B * C, (HW + 1023) / 1024), dim3(256), 0, st, y, gamma, beta, mask, stats, out, C, HW, W, cpg);
     NCHK(hipGetLastError());
     return GTTS_OK;
+}
+
+extern "C" size_t gtts_gn_mish_stats_floats(int B, int groups) {
+    return B > 0 && groups > 0 ? (size_t)B * groups * 2 + (size_t)B * groups * GN_SPLIT * 4 : 0;
 }
 
 extern "C" size_t gtts_gn_mish_scratch_bytes(int B, int C) { return B > 0 && C > 0 ? (size_t)B * C * 2 * 4 * 2 : 0; }

@@ -10,7 +10,8 @@
 // no unaligned LDS access and no second copy of the tile.  Precision: split-bf16, 3 MFMAs per product, fp32 accumulate.
 // Parallelism over pixels: `nslice` workgroups per (co tile, ci tile) each own a contiguous range of chunks and write their
 // 64 x 64 x 9 partial tile to the workspace; a second kernel adds the slices in a fixed order (deterministic, no atomics)
-// and writes the reference layout [cout][cin][3][3].  The bias gradient is a separate fixed-order reduction of dy.
+// and writes the reference layout [cout][cin][3][3].  The bias gradient falls out of the dy staging (every staged value is summed
+// by the thread that stages it; the ci-tile-0 workgroups publish per-slice partials, reduced in the same second kernel).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -28,6 +29,7 @@ struct Wgrad2Args {
     const float *mask;     // [B][W] or nullptr
     const float *dy;       // [B][cout][H][W]
     float *part;           // [nslice][tiles][9][64 co][64 ci]
+    float *dbpart;         // [nslice][cout] partial bias gradients (written by the ci-tile-0 workgroups), or nullptr
     int B, cin, cout, H, W;
     int ncx, ncy;          // chunks per row (ceil(W / 32)) and per column (ceil(H / 2))
     int nchunk;            // B * ncy * ncx
@@ -72,11 +74,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad2_kernel(const Wgrad2Args
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ky][kx][r] = 0.f;
 
+    float bsum[2] = {0.f, 0.f};            // bias gradient: this thread's dy items belong to co = (tid >> 3) + 32 k
     const int per = (a.nchunk + a.nslice - 1) / a.nslice;
     const int c_begin = slice * per, c_end = min(a.nchunk, c_begin + per);
     for (int ch = c_begin; ch < c_end; ++ch) {
         const int cx = ch % a.ncx, cy = (ch / a.ncx) % a.ncy, b = ch / (a.ncx * a.ncy);
         const int x0 = cx * 32, y0 = cy * 2;
+        // this thread's x items all cover the same 8 columns (block tid & 3): their mask values are loaded once per chunk
+        float mk[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mk[i] = a.mask ? a.mask[(size_t)b * a.W + min(x0 + 8 * (tid & 3) + i, a.W - 1)] : 1.f;
         const float *mrow = a.mask ? a.mask + (size_t)b * a.W : nullptr;
         __syncthreads();                    // the previous chunk's fragment reads are done
         // ---- stage dy: 512 items (co, row, block)
@@ -90,6 +97,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad2_kernel(const Wgrad2Args
             for (int i = 0; i < 8; ++i) {
                 const bool ok = y < a.H && px + i < a.W;
                 v[i] = ok ? p[min(px + i, a.W - 1)] : 0.f;
+                bsum[k] += v[i];
             }
             u32x4 hi, lo;
             split8(v, hi, lo);
@@ -108,9 +116,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad2_kernel(const Wgrad2Args
             for (int i = 0; i < 8; ++i) {
                 const bool ok = rowok && px + i < a.W;
                 const int pc = min(px + i, a.W - 1);
-                float t = ok ? p[pc] : 0.f;
-                if (mrow) t *= mrow[pc];
-                v[i] = t;
+                v[i] = (ok ? p[pc] : 0.f) * mk[i];
             }
             u32x4 hi, lo;
             split8(v, hi, lo);
@@ -181,47 +187,50 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad2_kernel(const Wgrad2Args
                 const int co = wm * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kg;
                 out[((ky * 3 + kx) * 64 + co) * 64 + wn * 32 + l31] = acc[ky][kx][rg];
             }
+    if (a.dbpart && ci0 == 0) {
+        // the 8 threads (row, block) of a co are consecutive lanes: fixed-order butterfly, lane 0 of each octet publishes
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float v = bsum[k];
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 4, 64);
+            if ((tid & 7) == 0) a.dbpart[(size_t)slice * a.cout + co0 + (tid >> 3) + 32 * k] = v;
+        }
+    }
 }
 
-// dW[co][ci][3][3] = sum over slices (fixed order).  grid (cout * cin / 256): thread = (co, ci) with ci fastest
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, int cin, int cout,
+// dW[co][ci][3][3] = sum over slices (fixed order).  One thread per partial-tile element (tile, tap, co, ci), ci fastest:
+// coalesced reads, eight slices in flight per thread; the last blocks of the grid reduce the bias partials the same way.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, const float *__restrict__ dbpart,
+                                                           float *__restrict__ dw, float *__restrict__ db, int cin, int cout,
                                                            int nslice) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= cin * cout) return;
-    const int ci = idx % cin, co = idx / cin;
     const int ncit = cin / 64, tiles = ncit * (cout / 64);
-    const int tile = (co / 64) * ncit + ci / 64;
-    const float *p = part + (size_t)tile * (9 * 64 * 64) + (co % 64) * 64 + (ci % 64);
-    float s[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) s[t] = 0.f;
-    for (int sl = 0; sl < nslice; ++sl) {
-        const float *q = p + (size_t)sl * tiles * (9 * 64 * 64);
-#pragma unroll
-        for (int t = 0; t < 9; ++t) s[t] += q[t * 64 * 64];
-    }
-#pragma unroll
-    for (int t = 0; t < 9; ++t) dw[(size_t)idx * 9 + t] = s[t];
-}
-
-// db[co] = sum_{b,y,x} dy: grid (cout), fixed order
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float *__restrict__ dy, float *__restrict__ db, int B, int cout, int HW) {
-    __shared__ double s_a[256];
-    const int co = blockIdx.x, tid = threadIdx.x;
-    double acc = 0.0;
-    for (int b = 0; b < B; ++b) {
-        const float *p = dy + ((size_t)b * cout + co) * HW;
+    const size_t tile_elems = 9 * 64 * 64, total = (size_t)tiles * tile_elems;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < total) {
+        const float *p = part + idx;
         float s = 0.f;
-        for (int i = tid; i < HW; i += 256) s += p[i];
-        acc += (double)s;
+        int sl = 0;
+        for (; sl + 8 <= nslice; sl += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(sl + u) * total];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; sl < nslice; ++sl) s += p[(size_t)sl * total];
+        const int tile = (int)(idx / tile_elems), e = (int)(idx % tile_elems);
+        const int tap = e / 4096, co = (tile / ncit) * 64 + (e >> 6) % 64, ci = (tile % ncit) * 64 + (e & 63);
+        dw[((size_t)co * cin + ci) * 9 + tap] = s;
+    } else if (db && dbpart) {
+        const size_t co = idx - total;
+        if (co < (size_t)cout) {
+            float s = 0.f;
+            for (int sl = 0; sl < nslice; ++sl) s += dbpart[(size_t)sl * cout + co];
+            db[co] = s;
+        }
     }
-    s_a[tid] = acc;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) s_a[tid] += s_a[tid + o];
-        __syncthreads();
-    }
-    if (tid == 0) db[co] = (float)s_a[0];
 }
 
 static void wgrad2_geometry(int B, int cin, int cout, int H, int W, Wgrad2Args &a) {
@@ -257,7 +266,7 @@ extern "C" size_t gtts_conv3x3_wgrad_workspace_bytes(int B, int cin, int cout, i
     if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || cin % 64 || cout % 64) return 0;
     Wgrad2Args a;
     wgrad2_geometry(B, cin, cout, H, W, a);
-    return (size_t)a.nslice * (cin / 64) * (cout / 64) * (9 * 64 * 64) * sizeof(float);
+    return ((size_t)a.nslice * (cin / 64) * (cout / 64) * (9 * 64 * 64) + (size_t)a.nslice * cout) * sizeof(float);
 }
 
 extern "C" int gtts_conv3x3_wgrad_tiled(const float *x, const float *mask, const float *dy, float *dw, float *db, void *workspace,
@@ -270,16 +279,15 @@ extern "C" int gtts_conv3x3_wgrad_tiled(const float *x, const float *mask, const
     wgrad2_geometry(B, cin, cout, H, W, a);
     const size_t need = gtts_conv3x3_wgrad_workspace_bytes(B, cin, cout, H, W);
     if (workspace_bytes < need) return wfail(GTTS_E_WORKSPACE, "gtts_conv3x3_wgrad_tiled: workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
-    a.x = x; a.mask = mask; a.dy = dy; a.part = (float *)workspace;
-    hipStream_t st = (hipStream_t)stream;
     const int tiles = (cin / 64) * (cout / 64);
+    a.x = x; a.mask = mask; a.dy = dy; a.part = (float *)workspace;
+    a.dbpart = db ? a.part + (size_t)a.nslice * tiles * (9 * 64 * 64) : nullptr;
+    hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(conv3x3_wgrad2_kernel, dim3((unsigned)(tiles * a.nslice)), dim3(256), 0, st, a);
     WCHK(hipGetLastError());
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((cin * cout + 255) / 256)), dim3(256), 0, st, a.part, dw, cin, cout, a.nslice);
+    const size_t total = (size_t)tiles * (9 * 64 * 64) + (db ? (size_t)cout : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.part, a.dbpart, dw, db, cin, cout,
+                       a.nslice);
     WCHK(hipGetLastError());
-    if (db) {
-        hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)cout), dim3(256), 0, st, dy, db, B, cout, H * W);
-        WCHK(hipGetLastError());
-    }
     return GTTS_OK;
 }
