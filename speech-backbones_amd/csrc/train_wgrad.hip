@@ -6,7 +6,8 @@
 // bf16 hi / lo planes ([channel][row][8-pixel block], a 16-byte slot per block; channel strides are odd numbers of slots:
 // conflict-free ds_read_b128).  The lane's 8 k-values are the 8 pixels of one block: the A fragment is one aligned read; the
 // B fragment of tap (ky, kx) is block (row + ky) for kx = 1 and, for kx = 0 / 2, the same block shifted by one PIXEL across the
-// packed pairs with v_alignbit_b32 (5 per plane give both shifted fragments) using the neighbouring blocks' edge dwords --
+// packed pairs with v_alignbit_b32 (5 per plane give both shifted fragments) using the neighbouring blocks' edge dwords (rows are
+// padded with one slot each side for the tile's edge columns, so those dwords sit at fixed offsets from every block) --
 // no unaligned LDS access and no second copy of the tile.  Precision: split-bf16, 3 MFMAs per product, fp32 accumulate.
 // Parallelism over pixels: `nslice` workgroups per (co tile, ci tile) each own a contiguous range of chunks and write their
 // 64 x 64 x 9 partial tile to the workspace; a second kernel adds the slices in a fixed order (deterministic, no atomics)
@@ -15,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 
@@ -22,11 +24,17 @@
 #include "common.h"
 #include "kernels.h"
 
+// WG_PF=1: prefetch the x items of chunk c + 1 in registers across the MFMAs of chunk c.  Measured slower (212 vs 201 us on the
+// 256 -> 256 layer): with 144 accumulator registers the 40 prefetch registers push the kernel into scratch.  Off.
+#ifndef WG_PF
+#define WG_PF 0
+#endif
+
 namespace gtts {
 
 struct Wgrad2Args {
     const float *x;        // [B][cin][H][W]
-    const float *mask;     // [B][W] or nullptr
+    const float *mask;     // [B][W]
     const float *dy;       // [B][cout][H][W]
     float *part;           // [nslice][tiles][9][64 co][64 ci]
     float *dbpart;         // [nslice][cout] partial bias gradients (written by the ci-tile-0 workgroups), or nullptr
@@ -37,7 +45,10 @@ struct Wgrad2Args {
 };
 
 constexpr int DY_STRIDE = 9;     // 16-byte slots per co: 2 rows x 4 blocks + 1 pad (odd)
-constexpr int X_STRIDE = 17;     // 16-byte slots per ci: 4 rows x 4 blocks + 1 pad (odd)
+constexpr int X_ROW = 6;         // 16-byte slots per (ci, row): a left pad slot, 4 blocks, a right pad slot -- the pads hold the
+                                 // edge columns x0 - 1 (last dword, high half) and x0 + 32 (first dword, low half), so that the
+                                 // neighbour dwords of EVERY block sit at fixed offsets from it (one address register per lane)
+constexpr int X_STRIDE = 25;     // 16-byte slots per ci: 4 rows x X_ROW + 1 pad (odd)
 
 __device__ __forceinline__ void split8(const float (&v)[8], u32x4 &hi, u32x4 &lo) {
     bf16x8 vh, vl;
@@ -53,9 +64,9 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4 &hi, u32x4 &lo
 }
 
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad2_kernel(const Wgrad2Args a) {
-    __shared__ __attribute__((aligned(16))) u32x4 s_dyh[64 * DY_STRIDE], s_dyl[64 * DY_STRIDE];
-    __shared__ __attribute__((aligned(16))) u32x4 s_xh[64 * X_STRIDE], s_xl[64 * X_STRIDE];
-    __shared__ unsigned s_eh[64 * 4 * 2], s_el[64 * 4 * 2];     // edge columns -1 / 32: [ci][row][side], element in the half used
+    extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
+    u32x4 *s_dyh = reinterpret_cast<u32x4 *>(wg_smem), *s_dyl = s_dyh + 64 * DY_STRIDE;
+    u32x4 *s_xh = s_dyl + 64 * DY_STRIDE, *s_xl = s_xh + 64 * X_STRIDE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kg = lane >> 5;
@@ -77,26 +88,95 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad2_kernel(const Wgrad2Args
     float bsum[2] = {0.f, 0.f};            // bias gradient: this thread's dy items belong to co = (tid >> 3) + 32 k
     const int per = (a.nchunk + a.nslice - 1) / a.nslice;
     const int c_begin = slice * per, c_end = min(a.nchunk, c_begin + per);
-    for (int ch = c_begin; ch < c_end; ++ch) {
+    // Global loads: 16-byte buffer loads at dword-aligned offsets (rows of an NCHW plane start anywhere), issued for chunk
+    // c + 1 right before the MFMAs of chunk c and consumed after them (registers: 4 + 2 items of 8 floats, 2 edge values,
+    // 8 mask values).  Columns past the row end alias the next row and are zeroed by selects; rows outside the image and
+    // whole items past the tensor read offset 0 and are zeroed the same way.
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)((size_t)a.B * a.cin * HW * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.dy), 0, (int)((size_t)a.B * a.cout * HW * 4), 0x00020000);
+    u32x4 xr[4][2], dr[2][2];
+    float er[2], mk[8];
+    // x (the bulk) and the mask values are prefetched across the MFMAs; dy and the edge columns are loaded at the top of the
+    // iteration and consumed after the x items have been split -- their latency hides behind that work without holding
+    // registers through the MFMA phase (the 144 accumulator registers leave room for one of the two)
+    auto issue_x = [&](int ch) {
         const int cx = ch % a.ncx, cy = (ch / a.ncx) % a.ncy, b = ch / (a.ncx * a.ncy);
         const int x0 = cx * 32, y0 = cy * 2;
-        // this thread's x items all cover the same 8 columns (block tid & 3): their mask values are loaded once per chunk
-        float mk[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) mk[i] = a.mask ? a.mask[(size_t)b * a.W + min(x0 + 8 * (tid & 3) + i, a.W - 1)] : 1.f;
-        const float *mrow = a.mask ? a.mask + (size_t)b * a.W : nullptr;
+        for (int i = 0; i < 8; ++i) mk[i] = a.mask[(size_t)b * a.W + min(x0 + 8 * (tid & 3) + i, a.W - 1)];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int item = tid + 256 * k, blk = item & 3, rr = (item >> 2) & 3, ci = item >> 4;
+            const int y = min(max(y0 - 1 + rr, 0), a.H - 1), px = min(x0 + 8 * blk, a.W - 1);
+            const int off = (int)((((size_t)b * a.cin + ci0 + ci) * HW + (size_t)y * a.W + px) * 4);
+            xr[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0);
+            xr[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rsx, off + 16, 0, 0);
+        }
+    };
+    auto issue_d = [&](int ch) {
+        const int cx = ch % a.ncx, cy = (ch / a.ncx) % a.ncy, b = ch / (a.ncx * a.ncy);
+        const int x0 = cx * 32, y0 = cy * 2;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int item = tid + 256 * k, blk = item & 3, r = (item >> 2) & 1, co = item >> 3;
+            const int y = min(y0 + r, a.H - 1), px = min(x0 + 8 * blk, a.W - 1);
+            const int off = (int)((((size_t)b * a.cout + co0 + co) * HW + (size_t)y * a.W + px) * 4);
+            dr[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rsd, off, 0, 0);
+            dr[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rsd, off + 16, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int item = tid + 256 * k, side = item & 1, rr = (item >> 1) & 3, ci = item >> 3;
+            const int y = y0 - 1 + rr, px = side ? x0 + 32 : x0 - 1;
+            const bool ok = y >= 0 && y < a.H && px >= 0 && px < a.W;
+            const int pc = min(max(px, 0), a.W - 1);
+            const float t = a.x[((size_t)b * a.cin + ci0 + ci) * HW + (size_t)(ok ? y : 0) * a.W + pc] * a.mask[(size_t)b * a.W + pc];
+            er[k] = ok ? t : 0.f;
+        }
+    };
+    // (bottom-tested by hand: with the exit test at the top hipcc copies all 144 accumulator registers around the loop)
+    if (c_begin < c_end) {
+#if WG_PF
+    issue_x(c_begin);
+#endif
+    int ch = c_begin;
+    do {
+        const int cx = ch % a.ncx, cy = (ch / a.ncx) % a.ncy;
+        const int x0 = cx * 32, y0 = cy * 2;
         __syncthreads();                    // the previous chunk's fragment reads are done
-        // ---- stage dy: 512 items (co, row, block)
+#if !WG_PF
+        issue_x(ch);
+#endif
+        issue_d(ch);
+        // ---- x * mask: 1024 main items (ci, row 0..3 = image rows y0-1..y0+2, block) -> bf16 hi / lo
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int item = tid + 256 * k, blk = item & 3, rr = (item >> 2) & 3, ci = item >> 4;
+            const int y = y0 - 1 + rr, px = x0 + 8 * blk;
+            const bool rowok = y >= 0 && y < a.H;
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned w = xr[k][i >> 2][i & 3];      // (copy first: __builtin_bit_cast of a vector ELEMENT reads element 0)
+                const float t = __builtin_bit_cast(float, w);
+                v[i] = (rowok && px + i < a.W) ? t * mk[i] : 0.f;
+            }
+            u32x4 hi, lo;
+            split8(v, hi, lo);
+            s_xh[ci * X_STRIDE + rr * X_ROW + 1 + blk] = hi;
+            s_xl[ci * X_STRIDE + rr * X_ROW + 1 + blk] = lo;
+        }
+        // ---- dy: 512 items (co, row, block)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int item = tid + 256 * k, blk = item & 3, r = (item >> 2) & 1, co = item >> 3;
             const int y = y0 + r, px = x0 + 8 * blk;
-            const float *p = a.dy + ((size_t)b * a.cout + co0 + co) * HW + (size_t)min(y, a.H - 1) * a.W;
             float v[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const bool ok = y < a.H && px + i < a.W;
-                v[i] = ok ? p[min(px + i, a.W - 1)] : 0.f;
+                const unsigned w = dr[k][i >> 2][i & 3];
+                const float t = __builtin_bit_cast(float, w);
+                v[i] = (y < a.H && px + i < a.W) ? t : 0.f;
                 bsum[k] += v[i];
             }
             u32x4 hi, lo;
@@ -104,41 +184,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad2_kernel(const Wgrad2Args
             s_dyh[co * DY_STRIDE + r * 4 + blk] = hi;
             s_dyl[co * DY_STRIDE + r * 4 + blk] = lo;
         }
-        // ---- stage x * mask: 1024 main items (ci, row 0..3 = image rows y0-1..y0+2, block)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int item = tid + 256 * k, blk = item & 3, rr = (item >> 2) & 3, ci = item >> 4;
-            const int y = y0 - 1 + rr, px = x0 + 8 * blk;
-            const bool rowok = y >= 0 && y < a.H;
-            const float *p = a.x + ((size_t)b * a.cin + ci0 + ci) * HW + (size_t)(rowok ? y : 0) * a.W;
-            float v[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const bool ok = rowok && px + i < a.W;
-                const int pc = min(px + i, a.W - 1);
-                v[i] = (ok ? p[pc] : 0.f) * mk[i];
-            }
-            u32x4 hi, lo;
-            split8(v, hi, lo);
-            s_xh[ci * X_STRIDE + rr * 4 + blk] = hi;
-            s_xl[ci * X_STRIDE + rr * 4 + blk] = lo;
-        }
         // ---- the two edge columns (x0 - 1 -> high half, x0 + 32 -> low half of the stored dword): 512 items
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int item = tid + 256 * k, side = item & 1, rr = (item >> 1) & 3, ci = item >> 3;
-            const int y = y0 - 1 + rr, px = side ? x0 + 32 : x0 - 1;
-            const bool ok = y >= 0 && y < a.H && px >= 0 && px < a.W;
-            const int pc = min(max(px, 0), a.W - 1);
-            float t = ok ? a.x[((size_t)b * a.cin + ci0 + ci) * HW + (size_t)(ok ? y : 0) * a.W + pc] : 0.f;
-            if (mrow) t *= mrow[pc];
             __bf16 h, l;
-            split_bf16(t, h, l);
+            split_bf16(er[k], h, l);
             const unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, h), lb = (unsigned)__builtin_bit_cast(unsigned short, l);
-            s_eh[item] = side ? hb : hb << 16;
-            s_el[item] = side ? lb : lb << 16;
+            const int di = (ci * X_STRIDE + rr * X_ROW + (side ? 5 : 0)) * 4 + (side ? 0 : 3);      // dword inside the pad slot
+            reinterpret_cast<unsigned *>(s_xh)[di] = side ? hb : hb << 16;
+            reinterpret_cast<unsigned *>(s_xl)[di] = side ? lb : lb << 16;
         }
         __syncthreads();
+#if WG_PF
+        issue_x(min(ch + 1, c_end - 1));    // unconditional prefetch behind the MFMAs (the last one is never used)
+#endif
         // ---- 4 k-steps of 16 pixels: (row r, column half cb); lane's block = 2 cb + kg
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -148,13 +208,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad2_kernel(const Wgrad2Args
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int rr = r + ky, ci = wn * 32 + l31;
-                const int bi = ci * X_STRIDE + rr * 4 + blk;
+                const int bi = ci * X_STRIDE + rr * X_ROW + 1 + blk;
                 const unsigned *xh32 = reinterpret_cast<const unsigned *>(s_xh), *xl32 = reinterpret_cast<const unsigned *>(s_xl);
                 const u32x4 dh = s_xh[bi], dl = s_xl[bi];
                 // P: dword holding the pixel left of the block in its HIGH half; N: dword holding the pixel right of it in its LOW half
-                const int ei = (ci * 4 + rr) * 2;
-                const unsigned Ph = blk > 0 ? xh32[(bi - 1) * 4 + 3] : s_eh[ei], Pl = blk > 0 ? xl32[(bi - 1) * 4 + 3] : s_el[ei];
-                const unsigned Nh = blk < 3 ? xh32[(bi + 1) * 4] : s_eh[ei + 1], Nl = blk < 3 ? xl32[(bi + 1) * 4] : s_el[ei + 1];
+                const unsigned Ph = xh32[bi * 4 - 1], Pl = xl32[bi * 4 - 1], Nh = xh32[bi * 4 + 4], Nl = xl32[bi * 4 + 4];
                 // shifted fragments: (e[-1], e0) (e1, e2) (e3, e4) (e5, e6)   and   (e1, e2) (e3, e4) (e5, e6) (e7, e[8])
                 const unsigned m1h = __builtin_amdgcn_alignbit(dh[1], dh[0], 16), m2h = __builtin_amdgcn_alignbit(dh[2], dh[1], 16),
                                m3h = __builtin_amdgcn_alignbit(dh[3], dh[2], 16);
@@ -175,6 +233,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad2_kernel(const Wgrad2Args
                 }
             }
         }
+    } while (++ch < c_end);
     }
     // ---- partial tile: D[m = co][n = ci]; lane (l31 = ci, kg) holds rows (rg&3) + 8 (rg>>2) + 4 kg
     float *out = a.part + ((size_t)slice * tiles + tile) * (9 * 64 * 64);
@@ -200,35 +259,46 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad2_kernel(const Wgrad2Args
     }
 }
 
-// dW[co][ci][3][3] = sum over slices (fixed order).  One thread per partial-tile element (tile, tap, co, ci), ci fastest:
-// coalesced reads, eight slices in flight per thread; the last blocks of the grid reduce the bias partials the same way.
+// dW[co][ci][3][3] = sum over slices (fixed order).  A workgroup owns 32 consecutive partial-tile elements (tile, tap, co, ci;
+// ci fastest: 128-byte rows) x 8 slice groups: every thread adds its group's slices with eight loads in flight, the groups are
+// combined through LDS in a fixed order.  The last workgroups of the grid reduce the bias partials the same way.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, const float *__restrict__ dbpart,
                                                            float *__restrict__ dw, float *__restrict__ db, int cin, int cout,
                                                            int nslice) {
+    __shared__ float s_red[8][32];
     const int ncit = cin / 64, tiles = ncit * (cout / 64);
     const size_t tile_elems = 9 * 64 * 64, total = (size_t)tiles * tile_elems;
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx < total) {
-        const float *p = part + idx;
-        float s = 0.f;
-        int sl = 0;
-        for (; sl + 8 <= nslice; sl += 8) {
+    const int e32 = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    const size_t idx = (size_t)blockIdx.x * 32 + e32;
+    const bool is_w = idx < total;                       // (total is a multiple of 32: a workgroup is all-weights or all-bias)
+    const size_t bco = idx - total;
+    const float *p = is_w ? part + idx : dbpart + (bco < (size_t)cout ? bco : 0);
+    const size_t stride = is_w ? total : (size_t)cout;
+    const int per = (nslice + 7) / 8, s0 = sg * per, s1 = min(nslice, s0 + per);
+    float s = 0.f;
+    if (is_w || (db && dbpart && bco < (size_t)cout)) {
+        int sl = s0;
+        for (; sl + 8 <= s1; sl += 8) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(sl + u) * total];
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(sl + u) * stride];
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += v[u];
         }
-        for (; sl < nslice; ++sl) s += p[(size_t)sl * total];
-        const int tile = (int)(idx / tile_elems), e = (int)(idx % tile_elems);
-        const int tap = e / 4096, co = (tile / ncit) * 64 + (e >> 6) % 64, ci = (tile % ncit) * 64 + (e & 63);
-        dw[((size_t)co * cin + ci) * 9 + tap] = s;
-    } else if (db && dbpart) {
-        const size_t co = idx - total;
-        if (co < (size_t)cout) {
-            float s = 0.f;
-            for (int sl = 0; sl < nslice; ++sl) s += dbpart[(size_t)sl * cout + co];
-            db[co] = s;
+        for (; sl < s1; ++sl) s += p[(size_t)sl * stride];
+    }
+    s_red[sg][e32] = s;
+    __syncthreads();
+    if (sg == 0) {
+        float t = s_red[0][e32];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) t += s_red[g][e32];
+        if (is_w) {
+            const int tile = (int)(idx / tile_elems), e = (int)(idx % tile_elems);
+            const int tap = e / 4096, co = (tile / ncit) * 64 + (e >> 6) % 64, ci = (tile % ncit) * 64 + (e & 63);
+            dw[((size_t)co * cin + ci) * 9 + tap] = t;
+        } else if (db && dbpart && bco < (size_t)cout) {
+            db[bco] = t;
         }
     }
 }
@@ -271,7 +341,7 @@ extern "C" size_t gtts_conv3x3_wgrad_workspace_bytes(int B, int cin, int cout, i
 
 extern "C" int gtts_conv3x3_wgrad_tiled(const float *x, const float *mask, const float *dy, float *dw, float *db, void *workspace,
                                         size_t workspace_bytes, int B, int cin, int cout, int H, int W, gtts_stream_t stream) {
-    if (!x || !dy || !dw || !workspace) return wfail(GTTS_E_NULL, "gtts_conv3x3_wgrad_tiled: null argument");
+    if (!x || !mask || !dy || !dw || !workspace) return wfail(GTTS_E_NULL, "gtts_conv3x3_wgrad_tiled: null argument");
     if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || cin % 64 || cout % 64)
         return wfail(GTTS_E_SHAPE, "gtts_conv3x3_wgrad_tiled: cin and cout must be multiples of 64 (got %d, %d)", cin, cout);
     if ((size_t)std::max(cin, cout) * H * W >= ((size_t)1 << 30)) return wfail(GTTS_E_SHAPE, "gtts_conv3x3_wgrad_tiled: tensor too large");
@@ -283,10 +353,18 @@ extern "C" int gtts_conv3x3_wgrad_tiled(const float *x, const float *mask, const
     a.x = x; a.mask = mask; a.dy = dy; a.part = (float *)workspace;
     a.dbpart = db ? a.part + (size_t)a.nslice * tiles * (9 * 64 * 64) : nullptr;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv3x3_wgrad2_kernel, dim3((unsigned)(tiles * a.nslice)), dim3(256), 0, st, a);
+    constexpr size_t smem = (size_t)(2 * 64 * DY_STRIDE + 2 * 64 * X_STRIDE) * 16;
+    static std::atomic<int> attr_set[64];        // hipFuncSetAttribute is per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev].load(std::memory_order_relaxed)) {
+        WCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wgrad2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set[dev].store(1, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(conv3x3_wgrad2_kernel, dim3((unsigned)(tiles * a.nslice)), dim3(256), smem, st, a);
     WCHK(hipGetLastError());
     const size_t total = (size_t)tiles * (9 * 64 * 64) + (db ? (size_t)cout : 0);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.part, a.dbpart, dw, db, cin, cout,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, a.part, a.dbpart, dw, db, cin, cout,
                        a.nslice);
     WCHK(hipGetLastError());
     return GTTS_OK;
