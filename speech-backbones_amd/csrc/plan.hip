@@ -1352,16 +1352,22 @@ extern "C" int gtts_log_prior(const float *mu_x, const float *y, float *log_prio
 }
 
 // ------------------------------------------------------------------------------------------------ measurement
-static std::string conv_kernel_name(int mode, int cin, int cout, int pro, int epi, int nsplit, bool abf = false) {
+// the template instance launch_conv picks (conv_mfma.hip: launch_prec / launch_cfg), as rocprofv3 prints it
+static std::string conv_kernel_name(int mode, int cin, int cout, int pro, int epi, int nsplit, bool abf, bool small) {
     const bool wide = cout > 64;
     const int kch = conv_geom(mode, cin, cout).kch;
+    const bool fullc = cin % 16 == 0;
     int wm, wn, mf;
     if (mode == CONV_DN) { wm = 2; wn = 2; mf = wide ? 2 : 1; }
     else if (wide) { wm = 2; wn = 2; mf = 2; }
     else { wm = 1; wn = 4; mf = 2; }
-    char buf[112];
-    snprintf(buf, sizeof buf, "gtts::conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d, %s>", mode, wm, wn, mf, kch, pro, epi, nsplit,
-             cin % 16 == 0 ? 1 : 0, abf ? "__bf16" : "float");
+    if (small && mode == CONV_C3 && fullc && !abf && nsplit > 1 && pro != PRO_IGLU) {      // half-height tiles (conv_small_tiles)
+        mf = 1;
+        if (wide) { wm = 4; wn = 1; } else { wm = 2; wn = 2; }
+    }
+    char buf[128];
+    snprintf(buf, sizeof buf, "gtts::conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d, %s, 2, 0>", mode, wm, wn, mf, kch, pro, epi, nsplit,
+             fullc ? 1 : 0, abf ? "__bf16" : "float");
     return buf;
 }
 
@@ -1400,7 +1406,7 @@ extern "C" int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, con
                 by = ab * B * (cin * Hi * Wi + o.cout * Ho * Wo);
                 if (o.epi == EPI_TAIL || o.epi == EPI_ATTN) by += ab * B * o.cout * Ho * Wo;
                 s_kernel = conv_kernel_name(o.mode, o.c0 + o.c1, o.cout, o.pro, o.epi, plan->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1,
-                                            plan->cfg.precision == GTTS_PREC_BF16_STORE);
+                                            plan->cfg.precision == GTTS_PREC_BF16_STORE, conv_small_tiles(o.mode, o.cout, Ho, Wo, B));
                 break;
             }
             case OP_GNFIN: s_kernel = "gtts::gn_finalize_kernel"; break;
