@@ -79,21 +79,32 @@ __global__ __launch_bounds__(256, (WM * MF == 1) ? 4 : (WM * MF == 2 ? 3 : 2)) v
     // Activations are prefetched TWO chunks ahead into two statically indexed register sets: a 1-D convolution has only
     // `taps` MFMA groups per chunk (a third of the 3x3 kernel's), so one chunk of MFMAs does not cover an HBM round trip.
     float araw2[PF2 ? 2 : 1][AITER][8];
+    // Buffer loads (the launcher requires cin % 16 == 0 -- every layer of the vocoder and the encoders -- and a sample below
+    // 2 GB): per-lane byte offset of (first channel of the item's 8-group, position), out-of-range items point past the
+    // descriptor and read 0, the chunk / channel offset rides in an SGPR -- no 64-bit VALU address arithmetic and no exec-mask
+    // branch per load (plain pointer loads under a validity select compile to one s_cbranch_execz per element)
+    const int xbytes = a.cin * a.Lin * 4;
+    const unsigned long long xaddr = reinterpret_cast<unsigned long long>(xb);
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void *>(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32)) << 32) |
+                                 (unsigned)__builtin_amdgcn_readfirstlane((unsigned)xaddr)),
+        0, __builtin_amdgcn_readfirstlane(xbytes), 0x00020000);
+    int it_voff[AITER];
+#pragma unroll
+    for (int it = 0; it < AITER; ++it) {
+        const int idx = tid + it * 256;
+        it_voff[it] = it_ok[it] ? (min(idx / NPX, NKG - 1) * 8 * a.Lin + it_pos[it]) * 4 : xbytes;
+    }
     auto load_act = [&](int chunk, auto set_c) {
         constexpr int SET = PF2 ? decltype(set_c)::value : 0;
         float (&araw)[AITER][8] = araw2[SET];
 #pragma unroll
-        for (int it = 0; it < AITER; ++it) {
-            const int idx = tid + it * 256;
-            const int kg = min(idx / NPX, NKG - 1);
-            const int cb = chunk * 16 + kg * 8;
+        for (int it = 0; it < AITER; ++it)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int c = min(cb + i, a.cin - 1);
-                const float v = (xb + it_pos[it])[c * a.Lin];
-                araw[it][i] = (it_ok[it] && cb + i < a.cin) ? v : 0.f;
+                const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(rsx, it_voff[it], (chunk * 16 + i) * a.Lin * 4, 0);
+                araw[it][i] = __builtin_bit_cast(float, u);
             }
-        }
     };
     u32x4 wregs[WITER];
     const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(a.w);
@@ -353,6 +364,7 @@ static inline hipError_t launch_conv1d(C1Args a, int mode, int K, int dil, hipSt
     while ((1 << a.ls) < a.S) ++a.ls;
     if ((1 << a.ls) != a.S) return hipErrorInvalidValue;
     if ((size_t)a.cout * a.Lin * a.S >= ((size_t)1 << 31)) return hipErrorInvalidValue;
+    if (a.cin % 16 != 0 || (size_t)a.cin * a.Lin * 4 >= ((size_t)1 << 31)) return hipErrorInvalidValue;   // buffer-load staging
     return g.tps == 3 ? launch_c1_t<3>(a, st) : launch_c1_t<4>(a, st);
 }
 
