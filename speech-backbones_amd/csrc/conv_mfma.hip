@@ -186,7 +186,11 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
     using C = ConvCfg<MODE, WM, WN, MF, KCH, NF>;
     static_assert(!PRIV || (MODE == CONV_C3 && FULLC && KCH == 1 && MF == 1), "private weight slices: 3x3, whole chunks, one fragment row per wave");
     constexpr int MT = C::MT, TR = C::TR, TC = C::TC, NST = C::NST, TPS = C::TPS, NKG = C::NKG;
-    constexpr int HC = C::HC, NPIX = C::NPIX, AITER = C::AITER, WBLK16 = C::WBLK16, WITER = C::WITER;
+    constexpr int HC = C::HC, NPIX = C::NPIX, AITER = C::AITER, WBLK16 = C::WBLK16;
+    // single-pass bf16 (NSPLIT == 1) multiplies with the hi halves only: the block's first half ([split][tap][kg][MT] order) is
+    // all it stages -- half the weight loads and LDS writes of a chunk
+    constexpr int NW16 = (NSPLIT == 1 && !ConvWdma<MODE, WM, FULLC>::on) ? WBLK16 / 2 : WBLK16;
+    constexpr int WITER = (NW16 + 255) / 256;
 
 #if GTTS_TRACE
     const unsigned long long tr_entry = __builtin_amdgcn_s_memtime();
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
         } else {
 #pragma unroll
             for (int i = 0; i < WITER; ++i)
-                wregs[i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (tid + i * 256) * 16, blk * (WBLK16 * 16), 0);
+                wregs[i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, min(tid + i * 256, NW16 - 1) * 16, blk * (WBLK16 * 16), 0);
         }
     };
 
@@ -557,7 +561,8 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
             } else {
                 if (stage > 0 || ADBUF) { GTTS_SYNC(); TR_MARK(5); }   // previous stage's MFMAs are done with s_w
 #pragma unroll
-                for (int i = 0; i < (GTTS_EXP == 4 ? 0 : WITER); ++i) s_w[tid + i * 256] = wregs[i];
+                for (int i = 0; i < (GTTS_EXP == 4 ? 0 : WITER); ++i)
+                    if (NW16 % 256 == 0 || tid + i * 256 < NW16) s_w[tid + i * 256] = wregs[i];
                 TR_MARK(2);
                 GTTS_SYNC();
                 TR_MARK(3);
