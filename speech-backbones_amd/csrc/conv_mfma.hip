@@ -456,10 +456,14 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
                     v = (ga * sg + tb[i]) * m;
                     if (!FULLC) v = (inb && i < nval) ? v : 0.f;
                 }
-                __bf16 h, l;
-                split_bf16(v, h, l);
-                vh[i] = h;
-                vl[i] = l;
+                if constexpr (NSPLIT > 1) {
+                    __bf16 h, l;
+                    split_bf16(v, h, l);
+                    vh[i] = h;
+                    vl[i] = l;
+                } else {
+                    vh[i] = (__bf16)v;           // single-pass bf16: no lo plane (neither computed nor written)
+                }
             }
             if constexpr (ADBUF) {
                 // branch-free (lanes without an item write a scratch slot): keeps the transform in the MFMAs' basic block
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
             } else if (has) {
                 const int slot = kg * NPIX + pr * HC + lc;
                 dh[slot] = *reinterpret_cast<u32x4 *>(&vh);
-                dl[slot] = *reinterpret_cast<u32x4 *>(&vl);
+                if constexpr (NSPLIT > 1) dl[slot] = *reinterpret_cast<u32x4 *>(&vl);
             }
         }
     };
