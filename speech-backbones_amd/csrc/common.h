@@ -68,6 +68,33 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_f<0x140>(v);     // row_mirror
     return (lane_f(v, 0) + lane_f(v, 16)) + (lane_f(v, 32) + lane_f(v, 48));
 }
+// V (8 or 16) independent wave-wide sums at once, "transposing": every step halves the number of live values instead of
+// reducing each of them across all 64 lanes -- v_permlane32_swap pairs lanes (l, l + 32) for value pairs (k, k + V/2),
+// v_permlane16_swap pairs (l, l + 16), four DPP steps finish inside the 16-lane rows: V/2 + V/4 swaps and V/2 + V/4 + V adds
+// instead of 11 V instructions.  On return out[k] (k < V/4) holds, in EVERY lane of row r = lane >> 4, the total of value
+// k + (V/4)(r & 1) + (V/2)(r >> 1).  Fixed association: deterministic, and the same for V = 8 and V = 16.
+template <int V>
+__device__ __forceinline__ void wave_sums_transposed(const float (&v)[V], float (&out)[V / 4]) {
+    static_assert(V == 8 || V == 16, "8 or 16 values");
+    float r1[V / 2];
+#pragma unroll
+    for (int k = 0; k < V / 2; ++k) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v[k]), __builtin_bit_cast(unsigned, v[k + V / 2]), false, false);
+        const unsigned x0 = sw[0], x1 = sw[1];          // (copy the elements first: bit_cast of a vector element reads element 0)
+        r1[k] = __builtin_bit_cast(float, x0) + __builtin_bit_cast(float, x1);
+    }
+#pragma unroll
+    for (int k = 0; k < V / 4; ++k) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, r1[k]), __builtin_bit_cast(unsigned, r1[k + V / 4]), false, false);
+        const unsigned x0 = sw[0], x1 = sw[1];
+        float t = __builtin_bit_cast(float, x0) + __builtin_bit_cast(float, x1);
+        t += dpp_f<0xB1>(t);      // quad_perm [1,0,3,2]
+        t += dpp_f<0x4E>(t);      // quad_perm [2,3,0,1]
+        t += dpp_f<0x141>(t);     // row_half_mirror
+        t += dpp_f<0x140>(t);     // row_mirror
+        out[k] = t;
+    }
+}
 __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_f<0xB1>(v));
     v = fmaxf(v, dpp_f<0x4E>(v));

@@ -734,17 +734,28 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
         const int gs = a.cout / a.groups;                   // channels per GroupNorm group
         // (s_red is not touched by the main loop: no barrier needed before writing it; the one below orders LDS only,
         // a full __syncthreads() would also wait for the 64 output stores of every lane to complete)
+        {
+            // all 8 MF wave sums in one transposing reduction (common.h); value index = which * 4 MF + mi * 4 + q
+            constexpr int V = 8 * MF;
+            float vals[V], tot[V / 4];
 #pragma unroll
-        for (int mi = 0; mi < MF; ++mi)
+            for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float s1 = wave_sum(st1[mi][q]);
-                float s2 = wave_sum(st2[mi][q]);
-                if (lane == 0) {
-                    s_red[((wave * MF + mi) * 4 + q) * 2 + 0] = s1;
-                    s_red[((wave * MF + mi) * 4 + q) * 2 + 1] = s2;
+                for (int q = 0; q < 4; ++q) {
+                    vals[mi * 4 + q] = st1[mi][q];
+                    vals[4 * MF + mi * 4 + q] = st2[mi][q];
+                }
+            wave_sums_transposed<V>(vals, tot);
+            if ((lane & 15) == 0) {
+                const int r = lane >> 4;
+#pragma unroll
+                for (int k = 0; k < V / 4; ++k) {
+                    const int vi = k + (V / 4) * (r & 1) + (V / 2) * (r >> 1);
+                    const int which = vi / (4 * MF), mi = (vi % (4 * MF)) >> 2, q = vi & 3;
+                    s_red[((wave * MF + mi) * 4 + q) * 2 + which] = tot[k];
                 }
             }
+        }
 #if GTTS_TRACE
         if (tr_on) tr_e[1] = __builtin_amdgcn_s_memtime();
 #endif
