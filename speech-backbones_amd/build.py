@@ -36,6 +36,8 @@ def build(force=False, verbose=False):
         if src not in os.environ.get("GTTS_NO_PERFILE", "").split(","):      # A/B builds
             cmd += PER_FILE_FLAGS.get(src, [])
         cmd += os.environ.get("GTTS_EXTRA_FLAGS", "").split()
+        if src == "conv_mfma.hip":
+            cmd += os.environ.get("GTTS_CONV_FLAGS", "").split()       # A/B builds of the convolution only
         cmd += ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
