@@ -250,6 +250,21 @@ def test_full_size_properties(S, dev):
     assert relerr(a[3:4].cpu(), ref) <= REL
 
 
+def test_batch_size_does_not_change_results(S, dev):
+    """Small launches tile the deep 3x3 layers with half-height tiles (conv_small_tiles): at T = 1024 one utterance alone
+    gets them (80 workgroups per layer), a sub-batch of two does not.  The GroupNorm partial sums of those layers are kept
+    per row pair, which both tilings produce identically -- so an utterance decoded alone must be BIT-identical to the same
+    utterance decoded inside a batch."""
+    sd, plan, blob = plan_for(S, dev, 0)
+    B, T = 6, 1024
+    inp = O.make_inputs(B, T, seed=77, ragged=True)
+    z, m, mu = inp["z"].to(dev), inp["mask"].to(dev), inp["mu"].to(dev)
+    full = plan.reverse_diffusion(blob, z, m, mu, 2)
+    for i in (0, 3, 5):
+        one = plan.reverse_diffusion(blob, z[i:i + 1].contiguous(), m[i:i + 1].contiguous(), mu[i:i + 1].contiguous(), 2)
+        assert torch.equal(one, full[i:i + 1]), "utterance %d differs between B=1 and B=%d" % (i, B)
+
+
 # ------------------------------------------------------------------------------------------------ drop-in modules
 def test_diffusion_module_drop_in(S, dev):
     M = importlib.import_module("speech-backbones_amd.model.diffusion")
