@@ -50,6 +50,18 @@ __device__ __forceinline__ void split_bf16(float x, __bf16 &h, __bf16 &l) {
     l = (__bf16)(x - (float)h);
 }
 
+// activation load / store through a buffer descriptor (per-lane byte offset + scalar byte offset), fp32 or bf16 storage
+template <typename AT>
+__device__ __forceinline__ float ld_act(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    if constexpr (sizeof(AT) == 4) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+    else return __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0) << 16);
+}
+template <typename AT>
+__device__ __forceinline__ void st_act(float v, __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    if constexpr (sizeof(AT) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs, voff, soff, 0);
+    else __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (__bf16)v), rs, voff, soff, 0);
+}
+
 // Wave-wide reductions on the DPP path (full-rate VALU, no LDS crossbar): __shfl_xor lowers to ds_bpermute_b32 plus an
 // lgkmcnt wait per step -- 12 dependent LDS round trips per 64-lane reduction, measured at ~11k cycles for the 16
 // reductions of the conv epilogue.  Butterfly inside a 16-lane row (quad_perm, row_half_mirror, row_mirror), then the
@@ -194,6 +206,13 @@ static inline size_t conv_packed_bytes(int mode, int cin, int cout) {
 }
 
 hipError_t launch_conv(int mode, const ConvArgs &a, hipStream_t st);
+// conv_ws.hip: the persistent wave-specialised Block convolution.  GTTS_WS=0 builds (A/B only) keep every layer on conv_mfma.hip.
+#ifndef GTTS_WS
+#define GTTS_WS 1
+#endif
+bool conv_ws_eligible(int mode, int c0, int c1, int cout, int pro, int epi);
+int conv_ws_nparts(int cout, int Hout, int Wout);      // GroupNorm partial slots per sample it writes (one per pixel tile)
+hipError_t launch_conv_ws(const ConvArgs &a, hipStream_t st);
 bool conv_small_tiles(int mode, int cout, int Hout, int Wout, int B);   // half-height tiles for launches smaller than the chip
 bool conv_rowpair_stats(int mode, int cout, int Hout, int Wout);        // GroupNorm partial slots per row pair (batch-size independent)
 

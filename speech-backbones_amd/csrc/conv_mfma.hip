@@ -122,18 +122,6 @@ extern "C" int gtts_debug_trace(unsigned long long *dst, int n) {
 
 namespace gtts {
 
-// activation load / store through a buffer descriptor (per-lane byte offset + scalar byte offset), fp32 or bf16 storage
-template <typename AT>
-__device__ __forceinline__ float ld_act(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
-    if constexpr (sizeof(AT) == 4) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
-    else return __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0) << 16);
-}
-template <typename AT>
-__device__ __forceinline__ void st_act(float v, __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
-    if constexpr (sizeof(AT) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs, voff, soff, 0);
-    else __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (__bf16)v), rs, voff, soff, 0);
-}
-
 template <int MODE, int WM, int WN, int MF, int KCH, int NF = 2>
 struct ConvCfg {
     static constexpr int MT = WM * MF * 32;
@@ -987,6 +975,8 @@ static hipError_t launch_prec(const ConvArgs &a, hipStream_t st) {
 
 hipError_t launch_conv(int mode, const ConvArgs &a, hipStream_t st) {
     const bool wide = a.cout > 64;
+    // Block convolutions on whole 16-channel chunks: the persistent wave-specialised kernel (conv_ws.hip)
+    if (conv_ws_eligible(mode, a.c0, a.c1, a.cout, a.pro, a.epi)) return launch_conv_ws(a, st);
     switch (mode) {
         case CONV_C3:
             if (a.epi == EPI_PLAIN) {          // DiffVC RefBlock convolutions (InstanceNorm statistics are a separate pass)

@@ -55,6 +55,7 @@ struct Tensor {
     int lvl;        // resolution level of a TK_ACT / TK_PART / TK_APART tensor
     size_t bytes;   // TK_BYTES_PERB
     int mode, cout; // TK_PART: conv geometry that produces it
+    bool ws;        // TK_PART: written by the wave-specialised kernel (conv_ws.hip): one slot per pixel tile of ITS tiling
     bool external;  // not in the workspace (inputs / outputs of the call)
     bool tref;      // frame axis is the reference mel's (T_ref) instead of T  (DiffVC RefBlock tensors)
     int first, last;
@@ -173,7 +174,7 @@ static size_t poff(const gtts_plan *p, const std::string &name) { return p->para
 static int add_tensor(gtts_plan *p, const std::string &name, int kind, int C, int lvl, bool external = false) {
     Tensor t;
     t.name = name; t.kind = kind; t.C = C; t.lvl = lvl; t.bytes = 0; t.mode = 0; t.cout = 0;
-    t.external = external; t.tref = false; t.first = 1 << 30; t.last = -1;
+    t.ws = false; t.external = external; t.tref = false; t.first = 1 << 30; t.last = -1;
     p->tensors.push_back(t);
     return (int)p->tensors.size() - 1;
 }
@@ -201,6 +202,7 @@ static void add_block(gtts_plan *p, const std::string &pre, const std::string &t
     int part = add_tensor(p, tname + ".part", TK_PART, p->cfg.groups, lvl);
     p->tensors[part].mode = CONV_C3;
     p->tensors[part].cout = cout;
+    p->tensors[part].ws = conv_ws_eligible(CONV_C3, c0, c1, cout, pro, EPI_STATS);
     *sc = add_tensor(p, tname + ".sc", TK_PERB, cout, 0);
     *sh = add_tensor(p, tname + ".sh", TK_PERB, cout, 0);
     Op c = blank_op(OP_CONV, tname + ".conv");
@@ -315,6 +317,13 @@ static void compute_liveness(gtts_plan *p) {
         const int ids[] = {o.src0, o.src1, o.sc, o.sh, o.w_t, o.bias_t, o.out, o.part, o.eh, o.esc, o.esh, o.eres,
                            o.apart, o.ctxn};
         for (int t : ids) touch(t, i);
+        // A Block convolution with the GroupNorm finalize fused in writes the finalize's scale / shift DURING this op (the
+        // sample that finishes first publishes while other workgroups still read this op's inputs): they are born here, not
+        // at the (skipped) finalize op -- otherwise first-fit may place them inside the region of an input that dies here.
+        if (o.kind == OP_CONV && o.gn_op >= 0) {
+            touch(p->ops[o.gn_op].sc, i);
+            touch(p->ops[o.gn_op].sh, i);
+        }
     }
     const int n = (int)p->ops.size();
     // tensors used outside the op program: alive for the whole call
@@ -654,7 +663,10 @@ static Layout compute_layout(const gtts_plan *p, int B, int T, int rows, int Tr)
     L.offsets.assign(n, 0);
     std::vector<size_t> sz(n);
     for (int i = 0; i < n; ++i) sz[i] = align_up(tensor_bytes(p, p->tensors[i], B, T, rows, Tr), 256);
-    size_t top = 0;
+    // 256 bytes of slack on both sides: the 16-byte halo loads of conv_ws.hip start one frame in front of a row and end up to
+    // three frames behind it (those frames are masked out, but the addresses must be mapped)
+    constexpr size_t PAD = 256;
+    size_t top = PAD;
     if (p->cfg.keep_intermediates) {
         for (int i = 0; i < n; ++i) { L.offsets[i] = top; top += sz[i]; }
     } else {
@@ -669,7 +681,7 @@ static Layout compute_layout(const gtts_plan *p, int B, int T, int rows, int Tr)
             // drop blocks whose tensor died before this one is first written
             live.erase(std::remove_if(live.begin(), live.end(), [&](const Blk &b) { return b.last < t.first; }), live.end());
             std::sort(live.begin(), live.end(), [](const Blk &a, const Blk &b) { return a.off < b.off; });
-            size_t pos = 0;
+            size_t pos = PAD;
             for (const Blk &b : live) {
                 if (pos + sz[id] <= b.off) break;
                 pos = std::max(pos, b.off + b.size);
@@ -679,7 +691,7 @@ static Layout compute_layout(const gtts_plan *p, int B, int T, int rows, int Tr)
             top = std::max(top, pos + sz[id]);
         }
     }
-    L.ws_bytes = top;
+    L.ws_bytes = top + PAD;
     return L;
 }
 
@@ -737,6 +749,11 @@ extern "C" int gtts_vc_tensor_info(const gtts_plan *plan, int i, int B, int T, i
         if (t.kind == TK_ROWS) { dims[0] = B; dims[1] = p->tmlp.tb_stride; }   // first B rows (estimator call)
     }
     return GTTS_OK;
+}
+
+// GroupNorm partial slots per sample of a TK_PART tensor (the count its producing kernel writes)
+static int part_slots(const Tensor &t, int H, int W) {
+    return t.ws ? conv_ws_nparts(t.cout, H, W) : conv_nparts(t.mode, t.cout, H, W);
 }
 
 // ------------------------------------------------------------------------------------------------ execution
@@ -836,7 +853,7 @@ static int run_ops(const RunCtx &c) {
                 const Tensor &pt = p->tensors[o.part];
                 hipError_t e = hipSuccess;
                 for (int rep = 0; rep < ((skip_op_mask() & 4) ? 2 : 1); ++rep)      // bit 2: launch twice (idempotent)
-                e = launch_gn_finalize(tptr(c, o.part), conv_nparts(pt.mode, pt.cout, H, W), p->cfg.groups, o.C,
+                e = launch_gn_finalize(tptr(c, o.part), part_slots(pt, H, W), p->cfg.groups, o.C,
                                                   H * W, (const float *)(c.blob + o.gamma_off),
                                                   (const float *)(c.blob + o.beta_off), tptr(c, o.sc), tptr(c, o.sh), c.B, c.st);
                 if (e != hipSuccess) return fail(GTTS_E_HIP, "gn_finalize %s: %s", o.label.c_str(), hipGetErrorString(e));
@@ -1353,8 +1370,13 @@ extern "C" int gtts_log_prior(const float *mu_x, const float *y, float *log_prio
 
 // ------------------------------------------------------------------------------------------------ measurement
 // the template instance launch_conv picks (conv_mfma.hip: launch_prec / launch_cfg), as rocprofv3 prints it
-static std::string conv_kernel_name(int mode, int cin, int cout, int pro, int epi, int nsplit, bool abf, bool small) {
+static std::string conv_kernel_name(int mode, int cin, int cout, int pro, int epi, int nsplit, bool abf, bool small, bool ws) {
     const bool wide = cout > 64;
+    if (ws) {      // conv_ws.hip (ring of 3 images: every Grad-TTS / DiffVC layer fits)
+        char wb[128];
+        snprintf(wb, sizeof wb, "gtts::conv3x3_ws_kernel<%d, %d, 2, 5, %d, %d, %s, 3>", wide ? 2 : 1, wide ? 2 : 4, pro, nsplit, abf ? "__bf16" : "float");
+        return wb;
+    }
     const int kch = conv_geom(mode, cin, cout).kch;
     const bool fullc = cin % 16 == 0;
     int wm, wn, mf;
@@ -1406,7 +1428,8 @@ extern "C" int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, con
                 by = ab * B * (cin * Hi * Wi + o.cout * Ho * Wo);
                 if (o.epi == EPI_TAIL || o.epi == EPI_ATTN) by += ab * B * o.cout * Ho * Wo;
                 s_kernel = conv_kernel_name(o.mode, o.c0 + o.c1, o.cout, o.pro, o.epi, plan->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1,
-                                            plan->cfg.precision == GTTS_PREC_BF16_STORE, conv_small_tiles(o.mode, o.cout, Ho, Wo, B));
+                                            plan->cfg.precision == GTTS_PREC_BF16_STORE, conv_small_tiles(o.mode, o.cout, Ho, Wo, B),
+                                            conv_ws_eligible(o.mode, o.c0, o.c1, o.cout, o.pro, o.epi));
                 break;
             }
             case OP_GNFIN: s_kernel = "gtts::gn_finalize_kernel"; break;

@@ -1,0 +1,10 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 300 python tools/ws_repro2.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/ws3_repro.txt
+for spec in "ws0 libgradtts_gfx950.so 0" "ws3 libgradtts_gfx950.so 3" "old3 libgtts_nows.so 3"; do
+  set -- $spec
+  GTTS_LIB=$PWD/speech-backbones_amd/$2 timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --per-op --streams $3 > gpurun_out/ws3_$1.json 2> gpurun_out/ws3_$1.txt
+  echo "== $1 rc=$? $(python -c "import json;d=json.load(open('gpurun_out/ws3_$1.json'));print(d['value'], d['config'].get('ms_per_unet_call'), (d.get('roofline') or {}).get('avg_us'))")"
+done
+grep -E "conv3x3_ws" gpurun_out/ws3_ws0.txt | tail -4
+for c in 128 256 64; do echo "--- trace cin=cout=$c"; GTTS_LIB=$PWD/speech-backbones_amd/libgtts_wstrace$c.so timeout 200 python tools/trace_ws.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/ws3_trace$c.txt; done

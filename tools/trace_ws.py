@@ -1,0 +1,37 @@
+"""Diagnostic: per-wave s_memtime sums of the wave-specialised 3x3 conv (library built with -DGTTS_DIAG -DGTTS_WS_TRACE=1)."""
+import ctypes, importlib, os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+S = importlib.import_module("speech-backbones_amd")
+from oracle import gradtts_oracle as O  # noqa: E402  (weights only; diagnostic)
+B, T = 16, 1024
+dev = torch.device("cuda:0")
+sd = O.make_estimator_state(seed=0)
+plan = S.Plan(n_spks=1, streams=0)
+packed = plan.pack(sd, dev)
+g = torch.Generator().manual_seed(0)
+x = torch.randn(B, 80, T, generator=g).to(dev)
+mu = torch.randn(B, 80, T, generator=g).to(dev)
+mask = torch.ones(B, 1, T, device=dev)
+t = torch.full((B,), 0.5, device=dev)
+for _ in range(2):
+    out = plan.estimator_forward(packed, x, mask, mu, t)
+torch.cuda.synchronize()
+lib = S._lib.lib()
+buf = (ctypes.c_ulonglong * 4096)()
+rc = lib.gtts_debug_trace_ws(buf, 4096)
+a = np.array(buf[:], dtype=np.float64).reshape(64, 8, 8)
+sel = a[:, 0, 4] > 0
+a = a[sel]
+print("rc", rc, "workgroups traced", a.shape[0], "(last traced launch of the call)")
+c, p = a[:, :4], a[:, 4:]
+items = c[:, :, 3].mean()
+print("consumer: items %.0f  total %.0f cycles" % (items, c[:, :, 4].mean()))
+for i, n in enumerate(["barrier wait", "chunk loops", "tile epilogues"]):
+    print("  %-16s %10.0f  per item %8.0f  (%4.1f%%)" % (n, c[:, :, i].mean(), c[:, :, i].mean() / items, 100 * c[:, :, i].mean() / c[:, :, 4].mean()))
+print("producer: total %.0f cycles" % p[:, :, 4].mean())
+for i, n in enumerate(["barrier wait", "staging", "re-request", "finish_tile"]):
+    print("  %-16s %10.0f  per item %8.0f  (%4.1f%%)" % (n, p[:, :, i].mean(), p[:, :, i].mean() / items, 100 * p[:, :, i].mean() / p[:, :, 4].mean()))
+print("  (first producer wave finish_tile: %.0f)" % p[:, 0, 3].mean())
