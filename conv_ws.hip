@@ -1,0 +1,825 @@
+// conv_ws.hip -- the Block 3x3 convolution (Grad-TTS/model/diffusion.py:49-58) as a PERSISTENT, WAVE-SPECIALISED kernel.
+//
+// Why a second kernel: conv_mfma.hip runs uniform waves (every wave loads, transforms, stages and multiplies); its
+// matrix pipe is 82 % busy inside the loop and 0.44 of peak over the launch (profiles/r02_conv_findings.txt): the VALU
+// work of the apply-on-load prologue (GroupNorm affine + Mish + mask + time bias + bf16 hi/lo split) sits in the same
+// instruction stream as the MFMAs, prologue / epilogue are exposed per tile and 2560 tiles quantise on 768 slots.
+// Here a workgroup is 8 waves on one CU (one workgroup per CU, 256 registers per lane):
+//   waves 0-3  CONSUMERS, one per SIMD: nothing but fragment reads (ds_read_b128), weight-fragment loads and MFMAs.
+//              Wave tile (MF x 32) channels x (NF rows x 32 frames) with MF x NF = 10 accumulators (160 registers);
+//              the three bf16x3 passes of a tap are issued pass-major over the ten accumulators, so two MFMAs on the
+//              same accumulator are ten issue slots apart (the per-accumulator order wl.xh, wh.xl, wh.xh -- and with it
+//              every output bit -- is that of conv_mfma.hip).  Weights never touch LDS: they are packed in fragment
+//              order (pack.hip), so a lane's A fragment is one coalesced 16-byte buffer load, prefetched one tap
+//              (30 MFMAs) ahead.
+//   waves 4-7  PRODUCERS: global loads of the halo tile of the next 16-channel chunk, the producer's epilogue
+//              (apply-on-load), the hi/lo split and the ds_write_b128 into a ring of activation images; their VALU
+//              instructions issue beside the consumers' MFMAs (separate pipes) instead of between them.  The first
+//              producer wave also combines the GroupNorm partial sums of a finished tile and runs the fused finalize.
+// One s_barrier per chunk hands an image over (ring of RING images, producers RING-1 chunks ahead).  The grid is
+// min(tiles, CUs) persistent workgroups walking tiles in XCD-banded order: the launch prologue is paid once per CU, and
+// the tile heights (10 rows for 128-channel tiles, 20 for 64) divide the 80 / 40 / 20 mel-bin levels, so B = 16 x 1024
+// frames is a whole number of rounds on 256 CUs on every level.
+//
+// The tiling is a function of the layer geometry only (never of the batch size) and the GroupNorm partial sums are
+// formed in a fixed order, so results do not depend on how utterances are batched.
+#include "common.h"
+#include "kernels.h"
+#include <algorithm>
+#include <atomic>
+#include <type_traits>
+
+// GTTS_WS_TRACE (diagnostic builds only, -DGTTS_DIAG): per-wave s_memtime sums of one layer (cin == cout == GTTS_TRACE_CIN)
+// read back with gtts_debug_trace_ws().  Consumer waves: [0] barrier wait, [1] chunk loops, [2] tile epilogues, [3] items, [4] total.
+// Producer waves: [0] barrier wait, [1] staging (load wait + transform + LDS write), [2] re-request (+ tile setup), [3] finish_tile.
+// GTTS_WS_EXP (diagnostic builds only): timing ablations, results are WRONG.  1: the consumers never reload weights,
+// 2: the producers never re-request activations, 3: the producers skip transform + LDS write, 4: the consumers never re-read
+// B fragments, 5: no MFMAs
+#ifndef GTTS_DIAG
+#undef GTTS_WS_TRACE
+#undef GTTS_WS_EXP
+#endif
+#ifndef GTTS_WS_EXP
+#define GTTS_WS_EXP 0
+#endif
+#ifndef GTTS_WS_TRACE
+#define GTTS_WS_TRACE 0
+#endif
+#ifndef GTTS_TRACE_CIN
+#define GTTS_TRACE_CIN 128
+#endif
+#if GTTS_WS_TRACE
+__device__ unsigned long long g_ws_trace[64 * 8 * 8];
+extern "C" int gtts_debug_trace_ws(unsigned long long *dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ws_trace), sizeof(unsigned long long) * (n < 4096 ? n : 4096));
+}
+#define WT_NOW() (tr_on ? __builtin_amdgcn_s_memtime() : 0ull)
+#define WT_ADD(slot, t1, t0) do { if (tr_on) tr_sum[slot] += (t1) - (t0); } while (0)
+#else
+#define WT_NOW() 0ull
+#define WT_ADD(slot, t1, t0) do { } while (0)
+#endif
+
+namespace gtts {
+
+template <int WM, int WN, int MF, int NF>
+struct WsCfg {
+    static constexpr int MT = WM * MF * 32;      // output channels per workgroup
+    static constexpr int TR = WN * NF;           // output rows per workgroup
+    static constexpr int HR = TR + 2, HC = 34;   // halo tile
+    static constexpr int NPIX = HR * HC;
+    static constexpr int NKG = 2;                // 8-channel groups per 16-channel chunk
+    static constexpr int NITEM = NKG * NPIX;     // (pixel, 8-channel group) staging items per chunk
+    static constexpr int AITER = (NITEM + 255) / 256;
+    static_assert(WM * WN == 4, "four consumer waves");
+};
+
+static inline size_t ws_smem_bytes(int npix, int nsplit, int ring, int cin, int pro, int mt, int mf) {
+    const size_t cpad = (size_t)((cin + 15) / 16) * 16;
+    return (size_t)ring * nsplit * 2 * npix * 16 + (pro == PRO_GN ? (size_t)2 * 3 * cpad * 4 : 0) + (size_t)2 * 4 * mf * 8 * 4 +
+           (size_t)2 * mt * 4;
+}
+
+template <int WM, int WN, int MF, int NF, int PRO, int NSPLIT, typename AT, int RING>
+__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs a) {
+    using C = WsCfg<WM, WN, MF, NF>;
+    constexpr int AB = (int)sizeof(AT);
+    constexpr int MT = C::MT, TR = C::TR, HC = C::HC, NPIX = C::NPIX, NKG = C::NKG, AITER = C::AITER;
+    constexpr int PLANE16 = NKG * NPIX;              // 16-byte units of one plane (hi or lo) of an image
+    constexpr int IMG16 = NSPLIT * PLANE16;          // ... of one ring slot
+    constexpr int D = RING - 1;                      // producers run D chunks ahead
+    constexpr int WBLK16 = 3 * MT * 2 * NKG;         // packed weight block (chunk, stage, cout tile): [split][tap][kg][MT] x 16 B
+    static_assert(PRO == PRO_MASK || PRO == PRO_GN, "Block prologues only");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4 *s_img = reinterpret_cast<u32x4 *>(smem);                      // [RING][split][kg][NPIX]
+    const int cpad = a.nchunk * 16;
+    float *s_par = reinterpret_cast<float *>(s_img + RING * IMG16);      // PRO_GN: [2 (tile parity)][3][cpad] scale, shift, time bias
+    float *s_red = s_par + (PRO == PRO_GN ? 2 * 3 * cpad : 0);           // [2 (tile parity)][4 waves][MF][4 octets][2]
+    float *s_epi = s_red + 2 * 4 * MF * 8;                               // [2 (tile parity)][MT] bias
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kg_l = lane >> 5;
+
+    // ---- persistent tile walk: workgroup position p in the XCD-banded order, tiles p, p + G, p + 2G, ...  (the 32 workgroups
+    // of an XCD work on 32 consecutive tiles at any time: cout tiles of one pixel tile, then row neighbours -> shared halo
+    // rows and the weights hit that XCD's L2)
+    const int ncot = a.cout / MT;
+    const int tps = a.tiles_x * a.tiles_y;              // pixel tiles per sample
+    const int ntiles = a.B * tps * ncot;
+    const int G = gridDim.x;
+    const int pos = xcd_slot(blockIdx.x, G);
+    const int my_tiles = pos < ntiles ? (ntiles - pos + G - 1) / G : 0;
+    const int nchunk = a.nchunk;
+    const int nitems = my_tiles * nchunk;
+    const int HW = a.Hin * a.Win;                       // 3x3, pad 1: output geometry == input geometry
+    struct TileId { int b, ty, tx, cot; };
+    auto decode = [&](int k) {                          // k-th tile of this workgroup
+        int t = pos + k * G;
+        t = t < ntiles ? t : ntiles - 1;
+        TileId r;
+        r.cot = t % ncot; t /= ncot;
+        r.ty = t % a.tiles_y; t /= a.tiles_y;
+        r.tx = t % a.tiles_x;
+        r.b = t / a.tiles_x;
+        return r;
+    };
+    auto uniform_rsrc = [](const void *p, int bytes) {
+        const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0,
+                                                 __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+    };
+
+#if GTTS_WS_TRACE
+    const bool tr_on = a.cin == GTTS_TRACE_CIN && a.cout == GTTS_TRACE_CIN && (blockIdx.x & 3) == 1;
+    unsigned long long tr_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long tr_entry = WT_NOW();
+#endif
+    if (wave < 4) {
+        // =================================================================================== CONSUMERS
+        __builtin_amdgcn_s_setprio(3);         // MFMA issue wins the per-SIMD arbitration against the producers' VALU stream
+        const int wm = wave / WN, wn = wave % WN;
+        const int m0 = wm * MF * 32;
+        const int wtotal = nchunk * 3 * ncot * WBLK16 * 16;
+        const __amdgpu_buffer_rsrc_t rsw = uniform_rsrc(a.w, wtotal);
+        const int w_voff = (kg_l * MT + m0 + l31) * 16;             // lane's row inside a (split, tap, kg) segment
+        // A fragments of (chunk, stage, tap) of cout tile cot: hi [mi], lo [MF + mi]
+        auto wload = [&](bf16x8 (&w)[MF * NSPLIT], int chunk, int stage, int tap, int cot) {
+            const int blk = (chunk * 3 + stage) * ncot + cot;
+#pragma unroll
+            for (int sp = 0; sp < NSPLIT; ++sp)
+#pragma unroll
+                for (int mi = 0; mi < MF; ++mi) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+                        rsw, w_voff + mi * 32 * 16, blk * (WBLK16 * 16) + ((sp * 3 + tap) * NKG * MT) * 16, 0);
+                    w[sp * MF + mi] = __builtin_bit_cast(bf16x8, v);
+                }
+        };
+        f32x16 acc[MF][NF];
+        // Issue order of a tap (bf16x3): pass 1 wl.xh, pass 2 wh.xh, pass 3 wh.xl, each pass over all MF x NF accumulators
+        // (two MFMAs on one accumulator are MF*NF issue slots apart).  Everything a pass multiplies was requested at least
+        // one pass (10 MFMAs, 320 cycles) earlier: xl of this tap at the start of pass 1, xh of the NEXT tap at the start
+        // of pass 3 (xh is dead after pass 2), the next tap's wl at the start of pass 2 (wl is dead after pass 1) and
+        // its wh -- into the second wh register set -- at the start of pass 1.  sched_barrier(0) between the passes pins
+        // that order (hipcc otherwise hoists the loads of all nine taps and spills); the waits it inserts are exact.
+        bf16x8 wh[MF], wl[MF], xh[NF];
+        TileId tl = decode(0);
+        // B-fragment base of this lane inside a plane (16-byte units): rows wn*NF.., column l31
+        const int x_lane = kg_l * NPIX + wn * NF * HC + l31;
+        auto wload_one = [&](bf16x8 (&w)[MF], int mi, int sp, int chunk, int stage, int tap, int cot) {
+            if (GTTS_WS_EXP == 1 && (chunk | stage | tap) != 0) return;
+            const int blk = (chunk * 3 + stage) * ncot + cot;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+                rsw, w_voff + mi * 32 * 16, blk * (WBLK16 * 16) + ((sp * 3 + tap) * NKG * MT) * 16, 0);
+            w[mi] = __builtin_bit_cast(bf16x8, v);
+        };
+        auto wload1 = [&](bf16x8 (&w)[MF], int sp, int chunk, int stage, int tap, int cot) {
+            if (GTTS_WS_EXP == 1 && (chunk | stage | tap) != 0) return;
+            const int blk = (chunk * 3 + stage) * ncot + cot;
+#pragma unroll
+            for (int mi = 0; mi < MF; ++mi) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+                    rsw, w_voff + mi * 32 * 16, blk * (WBLK16 * 16) + ((sp * 3 + tap) * NKG * MT) * 16, 0);
+                w[mi] = __builtin_bit_cast(bf16x8, v);
+            }
+        };
+        // ---- tile epilogue, hidden behind MFMAs.  The CU's write path takes 8 cycles per 128-byte line -- 10k cycles for a
+        // 128-channel tile -- and with one consumer wave per SIMD the matrix pipe would idle for that long after every tile
+        // (5 % of a 256-channel tile's life, 16 % of a 64-channel one's).  So the LAST chunk of a tile is walked one
+        // accumulator row (mi) at a time: when the 135 MFMAs of row 1 run, the 80 finished values of row 0 get their bias,
+        // statistics and stores, one (octet, row) group of four per pass; the FIRST chunk of the NEXT tile is walked the same
+        // way and takes care of row 1.  Middle chunks stay tap-major (weights of both rows, fragments read once).  The group
+        // code is branch-free (a lane outside the image stores to an out-of-range buffer offset, which the hardware drops, and
+        // adds zeros to the sums), so it shares the MFMAs' basic blocks and hipcc interleaves it.
+        struct EpiCtx { __amdgpu_buffer_rsrc_t rs_out; int ch0, y0, voff0, par; bool col_ok; };
+        auto make_ctx = [&](const TileId &t, int kk) {
+            EpiCtx c;
+            c.rs_out = uniform_rsrc(reinterpret_cast<AT *>(a.out) + (size_t)t.b * a.cout * HW, a.cout * HW * AB);
+            c.ch0 = t.cot * MT + m0;
+            c.y0 = t.ty * TR + wn * NF;
+            const int ox = t.tx * 32 + l31;
+            c.col_ok = ox < a.Wout;
+            c.voff0 = (c.y0 * a.Wout + ox + 4 * kg_l * HW) * AB;
+            c.par = kk & 1;
+            return c;
+        };
+        float st1[4], st2[4];                                       // GroupNorm sums of the accumulator row that is going out
+        bf16x8 whn[MF] = {};
+        auto epi_group = [&](const EpiCtx &c, int mi, int g) {      // g = q * NF + ni: four channels (octet q, this lane's half) of row ni
+            const int q = g / NF, ni = g - q * NF;
+            const bool ok = c.col_ok && c.y0 + ni < a.Hout;
+            const int voff = ok ? c.voff0 + ni * a.Wout * AB : 0x7ffffff0;       // out of range: the store is dropped
+            const int soff = (c.ch0 + mi * 32 + 8 * q) * HW * AB;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float r = acc[mi][ni][4 * q + e];             // (the bias is in the accumulator since the tile's first chunk)
+                const float rz = ok ? r : 0.f;
+                st1[q] += rz;
+                st2[q] += rz * rz;
+                st_act<AT>(r, c.rs_out, voff, soff + e * HW * AB);
+            }
+        };
+        // a tile's accumulators start at the bias (row mi of the current tile)
+        auto acc_init = [&](int mi, int par) {
+            const float *bias_l = s_epi + par * MT + m0 + 4 * kg_l + mi * 32;
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) {
+                const float bv = bias_l[(rg & 3) + 8 * (rg >> 2)];
+#pragma unroll
+                for (int ni = 0; ni < NF; ++ni) acc[mi][ni][rg] = bv;
+            }
+        };
+        auto epi_zero = [&]() {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { st1[q] = 0.f; st2[q] = 0.f; }
+        };
+        auto epi_finish = [&](int kk, int mi) {                     // wave sums of row mi of tile ordinal kk -> s_red[kk & 1]
+            float vals[8], tot[2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { vals[q] = st1[q]; vals[4 + q] = st2[q]; }
+            wave_sums_transposed<8>(vals, tot);
+            if ((lane & 15) == 0) {
+                const int r = lane >> 4;
+#pragma unroll
+                for (int kq = 0; kq < 2; ++kq) {
+                    const int vi = kq + 2 * (r & 1) + 4 * (r >> 1);
+                    const int which = vi >> 2, q = vi & 3;
+                    s_red[(kk & 1) * (4 * MF * 8) + ((wave * MF + mi) * 4 + q) * 2 + which] = tot[kq];
+                }
+            }
+        };
+        // One tap for the accumulator rows [MI0, MI1): pass 1 wl.xh, pass 2 wh.xh, pass 3 wh.xl.  The caller's hooks request what
+        // the NEXT tap multiplies (pf_wh: its wh fragments, at the start of pass 1; pf_wl(mi): its wl[mi], as soon as the MFMAs
+        // that use wl[mi] are issued; pf_xh: its xh fragments, at the start of pass 3) and may add an epilogue group per pass.
+        auto tap = [&](auto mi0c, auto mi1c, const u32x4 *xh_p, const u32x4 *xl_p, int st, int j, auto &&pf_wh, auto &&pf_wl,
+                       auto &&pf_xh, auto &&hook) {
+            constexpr int MI0 = decltype(mi0c)::value, MI1 = decltype(mi1c)::value;
+            bf16x8 xl[NF], xhn[NF];
+            pf_wh();
+            if (NSPLIT > 1) {
+#pragma unroll
+                for (int ni = 0; ni < NF; ++ni) xl[ni] = *reinterpret_cast<const bf16x8 *>(xl_p + (ni + st) * HC + j);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            hook(0);
+            if (NSPLIT > 1) {
+#pragma unroll
+                for (int mi = MI0; mi < MI1; ++mi) {
+#pragma unroll
+                    for (int ni = 0; ni < NF; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[mi], xh[ni], acc[mi][ni], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    pf_wl(mi);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            hook(1);
+#pragma unroll
+            for (int mi = MI0; mi < MI1; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NF; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[mi], xh[ni], acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            pf_xh(xhn);
+            __builtin_amdgcn_sched_barrier(0);
+            hook(2);
+            if (NSPLIT > 1) {
+#pragma unroll
+                for (int mi = MI0; mi < MI1; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NF; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[mi], xl[ni], acc[mi][ni], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mi = MI0; mi < MI1; ++mi) wh[mi] = whn[mi];
+#pragma unroll
+            for (int ni = 0; ni < NF; ++ni) xh[ni] = xhn[ni];
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        auto read_xh = [&](bf16x8 (&d)[NF], const u32x4 *p, int st, int j) {
+#pragma unroll
+            for (int ni = 0; ni < NF; ++ni) d[ni] = *reinterpret_cast<const bf16x8 *>(p + (ni + st) * HC + j);
+        };
+        // One accumulator row (mi) of a chunk, all nine taps; hook_sl(slot) is called once per pass (slot = tap * 3 + pass).
+        // After row 0 comes row 1 of the same chunk (its first-tap fragments are requested during row 0's last tap); after
+        // row 1 the first tap of chunk ncn of cout tile cot_n, both rows (a tile's first chunk only uses row 0's).
+        auto row_phase = [&](auto mic, const u32x4 *xh_p, const u32x4 *xl_p, const u32x4 *xn_p, int cc, int cot, int ncn, int cot_n,
+                             auto &&hook_sl) {
+            constexpr int mi = decltype(mic)::value;
+#pragma unroll
+            for (int st = 0; st < 3; ++st)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const bool last_t = st == 2 && j == 2;
+                    const int nst = j == 2 ? st + 1 : st, nj = j == 2 ? 0 : j + 1;
+                    const int t9 = st * 3 + j;
+                    auto pf_wh = [&]() {
+                        if (!last_t) wload_one(whn, mi, 0, cc, nst, nj, cot);
+                        else if (mi == 0) {
+                            wload_one(whn, 1, 0, cc, 0, 0, cot);
+                            if (NSPLIT > 1) wload_one(wl, 1, 1, cc, 0, 0, cot);
+                        } else {
+                            wload_one(whn, 0, 0, ncn, 0, 0, cot_n);
+                            wload_one(whn, 1, 0, ncn, 0, 0, cot_n);
+                            if (NSPLIT > 1) wload_one(wl, 0, 1, ncn, 0, 0, cot_n);
+                        }
+                    };
+                    auto pf_wl = [&](int m) {
+                        if (!last_t) wload_one(wl, m, 1, cc, nst, nj, cot);
+                        else if (mi == 1) wload_one(wl, 1, 1, ncn, 0, 0, cot_n);
+                    };
+                    auto pf_xh = [&](bf16x8 (&d)[NF]) {
+                        if (!last_t) read_xh(d, xh_p, nst, nj);
+                        else if (mi == 0) read_xh(d, xh_p, 0, 0);
+                        else read_xh(d, xn_p, 0, 0);
+                    };
+                    tap(std::integral_constant<int, mi>{}, std::integral_constant<int, mi + 1>{}, xh_p, xl_p, st, j, pf_wh, pf_wl, pf_xh,
+                        [&](int pass) { hook_sl(t9 * 3 + pass); });
+                    if (last_t) wh[1 - mi] = whn[1 - mi];
+                }
+        };
+        auto no_hook = [](int) {};
+        lds_barrier();                                              // (P) prologue barrier: s_par of tile 0 is written
+        int k = 0, cc = 0, slot = 0;
+        TileId tp = tl;                                             // previous tile (row 1 of it is stored during this tile's first chunk)
+        for (int i = 0; i < nitems; ++i) {
+            [[maybe_unused]] const unsigned long long tw0 = WT_NOW();
+            lds_barrier();                                          // image of item i is complete; everybody is done with item i - 1
+            [[maybe_unused]] const unsigned long long tw1 = WT_NOW();
+            WT_ADD(0, tw1, tw0);
+            const u32x4 *xh_p = s_img + slot * IMG16 + x_lane;
+            const u32x4 *xl_p = xh_p + PLANE16;
+            slot = slot + 1 == RING ? 0 : slot + 1;
+            const u32x4 *xn_p = s_img + slot * IMG16 + x_lane;     // next item's image (complete since the last barrier)
+            const bool last_c = cc + 1 == nchunk;
+            if (cc == 0) {
+                // ---------------- first chunk of a tile: row 0, with the previous tile's row 1 going out, then row 1
+                if (i == 0) {
+                    // the launch starts cold: first fragments requested here
+                    wload_one(wh, 0, 0, 0, 0, 0, tl.cot);
+                    if (NSPLIT > 1) wload_one(wl, 0, 1, 0, 0, 0, tl.cot);
+                    read_xh(xh, xh_p, 0, 0);
+                }
+                // (every wave stages the 64 bias values of ITS channels and reads them back itself: LDS executes a wave's
+                // accesses in order, no barrier needed; waves of one channel half write the same values)
+                s_epi[(k & 1) * MT + m0 + lane] = a.bias[tl.cot * MT + m0 + lane];
+                acc_init(0, k & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (k > 0) {
+                    const EpiCtx cp = make_ctx(tp, k - 1);
+                    epi_zero();
+                    row_phase(I0{}, xh_p, xl_p, xn_p, 0, tl.cot, 1, tl.cot, [&](int sl) { if (sl < 4 * NF) epi_group(cp, 1, sl); });
+                    epi_finish(k - 1, 1);                           // read by the first producer wave after the next barrier
+                } else {
+                    row_phase(I0{}, xh_p, xl_p, xn_p, 0, tl.cot, 1, tl.cot, no_hook);
+                }
+                acc_init(1, k & 1);
+                row_phase(I1{}, xh_p, xl_p, xn_p, 0, tl.cot, 1, tl.cot, no_hook);
+            } else if (!last_c) {
+                // ---------------- middle chunk: tap-major over both rows
+#pragma unroll
+                for (int st = 0; st < 3; ++st)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const bool last_t = st == 2 && j == 2;
+                        const int nst = j == 2 ? st + 1 : st, nj = j == 2 ? 0 : j + 1;
+                        auto pf_wh = [&]() {
+#pragma unroll
+                            for (int mi = 0; mi < MF; ++mi) {
+                                if (last_t) wload_one(whn, mi, 0, cc + 1, 0, 0, tl.cot); else wload_one(whn, mi, 0, cc, nst, nj, tl.cot);
+                            }
+                        };
+                        auto pf_wl = [&](int m) {
+                            if (last_t) wload_one(wl, m, 1, cc + 1, 0, 0, tl.cot); else wload_one(wl, m, 1, cc, nst, nj, tl.cot);
+                        };
+                        auto pf_xh = [&](bf16x8 (&d)[NF]) {
+                            if (last_t) read_xh(d, xn_p, 0, 0); else read_xh(d, xh_p, nst, nj);
+                        };
+                        tap(I0{}, I2{}, xh_p, xl_p, st, j, pf_wh, pf_wl, pf_xh, [&](int) {});
+                    }
+            } else {
+                // ---------------- last chunk: row 0, then row 1 with row 0 going out
+                const EpiCtx cx = make_ctx(tl, k);
+                const TileId tn = decode(k + 1);
+                row_phase(I0{}, xh_p, xl_p, xn_p, cc, tl.cot, 0, tn.cot, no_hook);
+                epi_zero();
+                row_phase(I1{}, xh_p, xl_p, xn_p, cc, tl.cot, 0, tn.cot, [&](int sl) { if (sl < 4 * NF) epi_group(cx, 0, sl); });
+                epi_finish(k, 0);
+            }
+            [[maybe_unused]] const unsigned long long tw2 = WT_NOW();
+            WT_ADD(1, tw2, tw1);
+            WT_ADD(3, 1ull, 0ull);
+            if (!last_c) { ++cc; continue; }
+            cc = 0;
+            tp = tl;
+            ++k;
+            tl = decode(k);
+        }
+        if (nitems > 0) {
+            // the launch's last tile: row 1 goes out with nothing to hide behind
+            const EpiCtx cp = make_ctx(tp, k - 1);
+            epi_zero();
+#pragma unroll
+            for (int g = 0; g < 4 * NF; ++g) epi_group(cp, 1, g);
+            epi_finish(k - 1, 1);
+        }
+        lds_barrier();                                              // (F) the last tile's wave sums are in s_red
+    } else {
+        // =================================================================================== PRODUCERS
+        const int ptid = tid - 256;
+        // A staging item is (8-channel group, halo row, GROUP OF FOUR consecutive frames): eight 16-byte loads (one per
+        // channel; 8 bytes in bf16 storage) instead of thirty-two dword loads -- the texture path spends its address cycles
+        // per instruction, and with dword loads the producers' requests alone kept it busy for a third of a chunk, in front of
+        // the consumers' weight-fragment loads.  Nine groups cover the 34 halo frames (the last one half); a group that
+        // straddles the image edge reads the neighbouring row's frames (valid memory) and the mask factor zeroes them.
+        constexpr int NG = 9;                         // frame groups per halo row
+        constexpr int NLI = NKG * C::HR * NG;         // lane-items per chunk
+        constexpr int LITER = (NLI + 255) / 256;
+        typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+        using RawV = typename std::conditional<AB == 4, u32x4, u32x2>::type;
+        struct Raw { RawV x[LITER][8]; };
+        Raw rawA, rawB;           // two chunks in flight: HBM latency is covered by a whole chunk of the consumers' MFMAs
+        int it_goff[LITER];       // load side: byte offset of (first channel of the 8-group, row, first frame of the group) in a chunk
+        float m_nxt[LITER][4];    // mask factors of the tile being REQUESTED (0 outside the image: the conv's zero padding) ...
+        float m_cur[LITER][4];    // ... and of the tile being STAGED (at most one tile behind)
+        int lk = 0, lc = 0, loaded = 0;      // tile ordinal / chunk of the next item to REQUEST, items requested
+        int sk = 0, sc_ = 0, staged = 0, ps = 0;   // ... of the next item to STAGE, items staged, ring slot
+        __amdgpu_buffer_rsrc_t rs0, rs1;
+        auto setup_tile = [&](const TileId &t) {
+            const int iy0 = t.ty * TR - 1, ix0 = t.tx * 32 - 1;
+#pragma unroll
+            for (int it = 0; it < LITER; ++it) {
+                const int idx = ptid + it * 256;
+                const bool has = idx < NLI;
+                const int kg = min(idx / (C::HR * NG), NKG - 1);
+                const int rem = idx - (idx / (C::HR * NG)) * (C::HR * NG);
+                const int pr = rem / NG, g = rem - pr * NG;
+                const int gy = iy0 + pr, gx0 = ix0 + 4 * g;
+                const bool row_in = has && gy >= 0 && gy < a.Hin;
+                // (+16: the descriptors below start 16 bytes in front of the sample's tensor -- the group left of the image edge
+                // starts one frame before its row, and a negative offset is out of range for all four frames of the load)
+                it_goff[it] = ((row_in ? gy : 0) * a.Win + gx0 + kg * 8 * HW) * AB + 16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int gx = gx0 + j;
+                    const bool in = row_in && gx >= 0 && gx < a.Win;
+                    const float m = a.mask[(size_t)t.b * a.T + ((size_t)(in ? gx : 0) << a.lvl_in)];
+                    m_nxt[it][j] = in ? m : 0.f;
+                }
+            }
+            const AT *sbase0 = reinterpret_cast<const AT *>(a.src0) + (size_t)t.b * a.c0 * HW;
+            const AT *sbase1 = a.c1 > 0 ? reinterpret_cast<const AT *>(a.src1) + (size_t)t.b * a.c1 * HW : sbase0;
+            rs0 = uniform_rsrc(reinterpret_cast<const char *>(sbase0) - 16, a.c0 * HW * AB + 16);
+            rs1 = uniform_rsrc(reinterpret_cast<const char *>(sbase1) - 16, (a.c1 > 0 ? a.c1 : a.c0) * HW * AB + 16);
+        };
+        auto write_params = [&](const TileId &t, int par) {
+            if constexpr (PRO == PRO_GN) {
+                float *sp = s_par + par * 3 * cpad;
+                for (int i = ptid; i < cpad; i += 256) {
+                    sp[i] = a.sc[(size_t)t.b * a.cin + i];
+                    sp[cpad + i] = a.sh[(size_t)t.b * a.cin + i];
+                    sp[2 * cpad + i] = a.tb ? a.tb[(size_t)t.b * a.tb_stride + i] : 0.f;
+                }
+            }
+        };
+        // Request side.  load_prep: at a tile switch the new tile's geometry, and its per-channel parameters into
+        // s_par[lk & 1] (the tile two back, which used that half, was staged completely long ago; the first reader is two
+        // staging steps = two barriers away); returns the scalar offset of the chunk.  load_one: one channel of one item.
+        struct LoadCtx { __amdgpu_buffer_rsrc_t rs; int soff; };
+        LoadCtx Lc;               // past the last item the previous request is simply repeated (never read): the loads stay
+                                  // unconditional straight-line code, so the waits hipcc counts in front of the transforms are exact
+        auto load_prep = [&]() {
+            if (loaded >= nitems) return;
+            if (lc == 0) {
+                const TileId t = decode(lk);
+                setup_tile(t);
+                write_params(t, lk & 1);
+            }
+            const int cb = lc * 16;
+            const bool first = cb < a.c0;
+            Lc.rs = first ? rs0 : rs1;
+            Lc.soff = (first ? cb : cb - a.c0) * HW * AB;
+            ++loaded;
+            if (++lc == nchunk) { lc = 0; ++lk; }
+        };
+        auto load_one = [&](Raw &R, int voff, int it, int i) {
+            if (GTTS_WS_EXP == 2) return;
+            if constexpr (AB == 4) R.x[it][i] = __builtin_amdgcn_raw_buffer_load_b128(Lc.rs, voff, Lc.soff + i * HW * AB, 0);
+            else R.x[it][i] = __builtin_amdgcn_raw_buffer_load_b64(Lc.rs, voff, Lc.soff + i * HW * AB, 0);
+        };
+        // Stage one item out of R into image dst and re-request R (the item two ahead) CHANNEL BY CHANNEL: the 16-byte load of
+        // channel i is issued as soon as its four frames are transformed.  Requested in one burst (32-64 KB per workgroup),
+        // the producers' loads queue in front of the consumers' weight-fragment loads in the CU's texture path for longer than
+        // those are prefetched ahead (measured: chunk loop 9.3k cycles without the burst, 10.0k / 12.4k with it).
+        auto stage_and_load = [&](Raw &R, int chunk, int par, u32x4 *dst) {
+            const float *sp = s_par + par * 3 * cpad;
+#pragma unroll
+            for (int it = 0; it < LITER; ++it) {
+                const int idx = ptid + it * 256;
+                const bool has = idx < NLI;
+                const int kg = min(idx / (C::HR * NG), NKG - 1);
+                const int rem = idx - (idx / (C::HR * NG)) * (C::HR * NG);
+                const int pr = rem / NG, g = rem - pr * NG;
+                const int cb = chunk * 16 + kg * 8;
+                float sc[8], sh[8], tb[8];
+                if constexpr (PRO == PRO_GN) {
+                    const float4 *q0 = reinterpret_cast<const float4 *>(sp + cb);
+                    const float4 *q1 = reinterpret_cast<const float4 *>(sp + cpad + cb);
+                    const float4 *q2 = reinterpret_cast<const float4 *>(sp + 2 * cpad + cb);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float4 u = q0[h], u1 = q1[h], u2 = q2[h];
+                        sc[4 * h + 0] = u.x; sc[4 * h + 1] = u.y; sc[4 * h + 2] = u.z; sc[4 * h + 3] = u.w;
+                        sh[4 * h + 0] = u1.x; sh[4 * h + 1] = u1.y; sh[4 * h + 2] = u1.z; sh[4 * h + 3] = u1.w;
+                        tb[4 * h + 0] = u2.x; tb[4 * h + 1] = u2.y; tb[4 * h + 2] = u2.z; tb[4 * h + 3] = u2.w;
+                    }
+                }
+                bf16x8 vh[4], vl[4];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (GTTS_WS_EXP != 3) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float v;
+                            if constexpr (AB == 4) {
+                                const unsigned u = R.x[it][i][j];
+                                v = __builtin_bit_cast(float, u);
+                            } else {
+                                const unsigned u = R.x[it][i][j >> 1];
+                                v = __builtin_bit_cast(float, (j & 1) ? (u & 0xffff0000u) : (u << 16));
+                            }
+                            const float m = m_cur[it][j];
+                            if constexpr (PRO == PRO_MASK) {
+                                v *= m;
+                            } else {
+                                const float y = v * sc[i] + sh[i];
+                                v = (mish_f(y) * m + tb[i]) * m;
+                            }
+                            if constexpr (NSPLIT > 1) {
+                                __bf16 h, l;
+                                split_bf16(v, h, l);
+                                vh[j][i] = h;
+                                vl[j][i] = l;
+                            } else {
+                                vh[j][i] = (__bf16)v;
+                            }
+                        }
+                    }
+                    // the re-request of channel i may not move ahead of its transform (hipcc otherwise copies the four values
+                    // aside and issues all eight loads first): an opaque dependence of the load's offset on the last result
+                    int voff = it_goff[it];
+                    if constexpr (NSPLIT > 1) asm volatile("" : "+v"(voff) : "v"(vl[0][i]), "v"(vl[1][i]), "v"(vl[2][i]), "v"(vl[3][i]));
+                    else asm volatile("" : "+v"(voff) : "v"(vh[0][i]), "v"(vh[1][i]), "v"(vh[2][i]), "v"(vh[3][i]));
+                    load_one(R, voff, it, i);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (GTTS_WS_EXP != 3) {
+                    u32x4 *drow = dst + kg * NPIX + pr * HC + 4 * g;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (has && 4 * g + j < HC) {
+                            drow[j] = *reinterpret_cast<u32x4 *>(&vh[j]);
+                            if constexpr (NSPLIT > 1) drow[PLANE16 + j] = *reinterpret_cast<u32x4 *>(&vl[j]);
+                        }
+                    }
+                }
+            }
+        };
+        auto load_all = [&](Raw &R) {      // (launch prologue only)
+            load_prep();
+#pragma unroll
+            for (int it = 0; it < LITER; ++it)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) load_one(R, it_goff[it], it, i);
+        };
+        // GroupNorm partial sums of a finished tile (the consumers' wave sums are in s_red[par]) + fused finalize; first
+        // producer wave only.  Slot = pixel tile; value order: octets of the group, then the WN wave rows -- fixed.
+        auto finish_tile = [&](const TileId &t, int par) {
+            const int gs = a.cout / a.groups;
+            const int gpw = MT / gs > 0 ? MT / gs : 1;
+            const float *red = s_red + par * (4 * MF * 8);
+            if (lane < gpw) {
+                const int g = (t.cot * MT) / gs + lane;
+                if (g < a.groups) {
+                    const int noct = (gs < MT ? gs : MT) >> 3, o0 = lane * noct;
+                    float s1 = 0.f, s2 = 0.f;
+                    for (int o = o0; o < o0 + noct; ++o) {
+                        const int f = o >> 2, q = o & 3, wmm = f / MF, mi = f - wmm * MF;
+#pragma unroll
+                        for (int wc = 0; wc < WN; ++wc) {
+                            const int w = wmm * WN + wc;
+                            s1 += red[((w * MF + mi) * 4 + q) * 2 + 0];
+                            s2 += red[((w * MF + mi) * 4 + q) * 2 + 1];
+                        }
+                    }
+                    const int pslot = t.tx * a.tiles_y + t.ty;
+                    float *p = a.partials + (((size_t)t.b * a.nparts + pslot) * a.groups + g) * 2;
+                    if (a.ticket != nullptr) {
+                        // write-through (sc1) stores + vmcnt drain + relaxed agent-scope ticket: see conv_mfma.hip (the agent-scope
+                        // release would write back every dirty output line of this XCD's L2)
+                        __hip_atomic_store(p, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(p + 1, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        p[0] = s1;
+                        p[1] = s2;
+                    }
+                }
+            }
+            if (a.ticket == nullptr) return;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(a.ticket + t.b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old != (unsigned)(tps * ncot) - 1) return;
+            // last tile of the sample: fixed-order fp64 reduction of ALL partials of the sample (sc1 loads), 8 lanes per group
+            const int b = t.b;
+            const int g = lane >> 3, sub = lane & 7;
+            double s1 = 0.0, s2 = 0.0;
+            if (g < a.groups) {
+                const float *pp = a.partials + ((size_t)b * a.nparts * a.groups + g) * 2;
+#pragma unroll 8
+                for (int i = sub; i < a.nparts; i += 8) {
+                    const unsigned long long u = __hip_atomic_load(
+                        reinterpret_cast<const unsigned long long *>(pp + (size_t)i * a.groups * 2), __ATOMIC_RELAXED,
+                        __HIP_MEMORY_SCOPE_AGENT);
+                    s1 += (double)__builtin_bit_cast(float, (unsigned)u);
+                    s2 += (double)__builtin_bit_cast(float, (unsigned)(u >> 32));
+                }
+            }
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                s1 += __shfl_xor(s1, o, 64);
+                s2 += __shfl_xor(s2, o, 64);
+            }
+            const double mean = s1 / (double)a.gn_count;
+            double var = s2 / (double)a.gn_count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const double rstd = 1.0 / sqrt(var + 1e-5);
+            if (g < a.groups) {
+                for (int c = g * gs + sub; c < (g + 1) * gs; c += 8) {
+                    const double sc = (double)a.gn_gamma[c] * rstd;
+                    a.gn_sc[(size_t)b * a.cout + c] = (float)sc;
+                    a.gn_sh[(size_t)b * a.cout + c] = (float)((double)a.gn_beta[c] - mean * sc);
+                }
+            }
+            if (lane == 0) __hip_atomic_store(a.ticket + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        };
+
+        // stage the next item out of R into ring slot ps while re-requesting R (the item two ahead)
+        auto step = [&](Raw &R) {
+            if (staged >= nitems) return;
+            [[maybe_unused]] const unsigned long long t0 = WT_NOW();
+            load_prep();
+            [[maybe_unused]] const unsigned long long t1 = WT_NOW();
+            stage_and_load(R, sc_, sk & 1, s_img + ps * IMG16);
+            ps = ps + 1 == RING ? 0 : ps + 1;
+            ++staged;
+            if (++sc_ == nchunk) {
+                sc_ = 0;
+                ++sk;
+#pragma unroll
+                for (int it = 0; it < LITER; ++it)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) m_cur[it][j] = m_nxt[it][j];      // (the load side is at most one tile ahead)
+            }
+#if GTTS_WS_TRACE
+            if (tr_on) __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the LDS writes are done (timing only)
+#endif
+            WT_ADD(2, t1, t0);
+            WT_ADD(1, WT_NOW(), t1);
+        };
+        auto fin = [&](int i) {       // during item i - 1, the first chunk of a tile, the consumers published the sums of the tile before
+            if (wave == 4 && i > 1 && i % nchunk == 1) {
+                const int kt = (i - 1) / nchunk - 1;
+                finish_tile(decode(kt), kt & 1);
+            }
+        };
+        load_all(rawA);
+#pragma unroll
+        for (int it = 0; it < LITER; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m_cur[it][j] = m_nxt[it][j];
+        load_all(rawB);
+        lds_barrier();                                 // (P) s_par of tile 0 visible to every producer wave
+        // D items ahead (host guarantees nchunk >= 2: the first two items share a tile, so s_par[0] is all they need);
+        // the register sets alternate A, B, A, ... from here on
+        step(rawA);
+        if (D > 1) step(rawB);
+        for (int i = 0; i < nitems; i += 2) {
+            [[maybe_unused]] unsigned long long tb0 = WT_NOW();
+            lds_barrier();
+            [[maybe_unused]] unsigned long long tb1 = WT_NOW();
+            WT_ADD(0, tb1, tb0);
+            fin(i);
+            WT_ADD(3, WT_NOW(), tb1);
+            if (D & 1) step(rawB); else step(rawA);
+            if (i + 1 < nitems) {
+                tb0 = WT_NOW();
+                lds_barrier();
+                tb1 = WT_NOW();
+                WT_ADD(0, tb1, tb0);
+                fin(i + 1);
+                WT_ADD(3, WT_NOW(), tb1);
+                if (D & 1) step(rawA); else step(rawB);
+            }
+        }
+        lds_barrier();                                 // (F)
+        if (wave == 4 && nitems > 0) finish_tile(decode(my_tiles - 1), (my_tiles - 1) & 1);
+    }
+#if GTTS_WS_TRACE
+    if (tr_on && lane == 0 && (blockIdx.x >> 2) < 64) {
+        tr_sum[4] = __builtin_amdgcn_s_memtime() - tr_entry;
+        for (int q = 0; q < 8; ++q) g_ws_trace[((blockIdx.x >> 2) * 8 + wave) * 8 + q] = tr_sum[q];
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------- host side
+// Which Block convolutions take this kernel: 3x3, whole 16-channel chunks (a concatenated input splitting on a chunk
+// boundary), mask / GroupNorm prologue, statistics epilogue, at least 32 input channels, whole cout tiles.
+bool conv_ws_eligible(int mode, int c0, int c1, int cout, int pro, int epi) {
+    const int cin = c0 + c1;
+    if (!GTTS_WS) return false;
+    if (mode != CONV_C3 || epi != EPI_STATS || (pro != PRO_MASK && pro != PRO_GN)) return false;
+    if (cin % 16 != 0 || cin < 32 || (c1 != 0 && c0 % 16 != 0)) return false;
+    return cout % 64 == 0 && (cout <= 64 || cout % 128 == 0);
+}
+// tile geometry of a layer (a function of the layer only, never of the batch)
+static inline void ws_tile(int cout, int *mt, int *tr) {
+    *mt = cout <= 64 ? 64 : 128;
+    *tr = cout <= 64 ? 20 : 10;
+}
+int conv_ws_nparts(int cout, int Hout, int Wout) {
+    int mt, tr;
+    ws_tile(cout, &mt, &tr);
+    return ((Wout + 31) / 32) * ((Hout + tr - 1) / tr);
+}
+
+template <int WM, int WN, int MF, int NF, int PRO, int NSPLIT, typename AT>
+static hipError_t launch_ws_ring(ConvArgs &a, hipStream_t st) {
+    using C = WsCfg<WM, WN, MF, NF>;
+    a.nchunk = a.cin / 16;
+    a.tiles_x = (a.Wout + 31) / 32;
+    a.tiles_y = (a.Hout + C::TR - 1) / C::TR;
+    a.nparts = a.tiles_x * a.tiles_y;
+    a.stat_rows = 0;
+    const size_t lim = (size_t)1 << 31;
+    if ((size_t)std::max(a.c0, a.c1) * a.Hin * a.Win * sizeof(AT) >= lim || (size_t)a.cout * a.Hout * a.Wout * sizeof(AT) >= lim)
+        return hipErrorInvalidValue;
+    static std::atomic<int> n_cu[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int cus = n_cu[dev].load(std::memory_order_relaxed);
+    if (cus == 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        n_cu[dev].store(cus, std::memory_order_relaxed);
+    }
+    const long ntiles = (long)a.B * a.tiles_x * a.tiles_y * (a.cout / C::MT);
+    const int grid = (int)std::min<long>(ntiles, cus);
+    const size_t smem3 = ws_smem_bytes(C::NPIX, NSPLIT, 3, a.cin, PRO, C::MT, MF);
+    const bool ring3 = smem3 <= (size_t)160 * 1024;
+    auto go = [&](auto kern, size_t smem) -> hipError_t {
+        static std::atomic<size_t> attr_set[64];
+        if (smem > attr_set[dev].load(std::memory_order_relaxed)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return e;
+            attr_set[dev].store(smem, std::memory_order_relaxed);
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, a);
+        return hipGetLastError();
+    };
+    if (ring3) return go(&conv3x3_ws_kernel<WM, WN, MF, NF, PRO, NSPLIT, AT, 3>, smem3);
+    const size_t smem2 = ws_smem_bytes(C::NPIX, NSPLIT, 2, a.cin, PRO, C::MT, MF);
+    if (smem2 > (size_t)160 * 1024) return hipErrorInvalidValue;
+    return go(&conv3x3_ws_kernel<WM, WN, MF, NF, PRO, NSPLIT, AT, 2>, smem2);
+}
+
+template <int PRO>
+static hipError_t launch_ws_pro(ConvArgs &a, hipStream_t st) {
+#ifdef GTTS_WS_PROBE      // compile-time probe builds (register / ISA inspection): one instantiation only
+    if constexpr (PRO == PRO_GN) return launch_ws_ring<2, 2, 2, 5, PRO_GN, 2, float>(a, st);
+    else return hipErrorInvalidValue;
+#else
+    const bool wide = a.cout > 64;
+    if (a.act_bf16) {
+        if (a.nsplit > 1) return hipErrorInvalidValue;
+        return wide ? launch_ws_ring<2, 2, 2, 5, PRO, 1, __bf16>(a, st) : launch_ws_ring<1, 4, 2, 5, PRO, 1, __bf16>(a, st);
+    }
+    if (a.nsplit > 1) return wide ? launch_ws_ring<2, 2, 2, 5, PRO, 2, float>(a, st) : launch_ws_ring<1, 4, 2, 5, PRO, 2, float>(a, st);
+    return wide ? launch_ws_ring<2, 2, 2, 5, PRO, 1, float>(a, st) : launch_ws_ring<1, 4, 2, 5, PRO, 1, float>(a, st);
+#endif
+}
+
+hipError_t launch_conv_ws(const ConvArgs &a_in, hipStream_t st) {
+    ConvArgs a = a_in;
+    if (!conv_ws_eligible(CONV_C3, a.c0, a.c1, a.cout, a.pro, a.epi)) return hipErrorInvalidValue;
+    return a.pro == PRO_GN ? launch_ws_pro<PRO_GN>(a, st) : launch_ws_pro<PRO_MASK>(a, st);
+}
+
+}  // namespace gtts

@@ -185,7 +185,9 @@ class Plan:
         """arch=0: Grad-TTS GradLogPEstimator2d; arch=1: DiffVC GradLogPEstimator (dim = dim_base).
 
         streams: number of sub-batches gtts_reverse_diffusion runs side by side on torch side streams owned by this
-        object and registered with gtts_plan_set_streams (0 / 1: no split; default 3, or $GTTS_STREAMS)."""
+        object and registered with gtts_plan_set_streams (0 / 1: no split; default 2, or $GTTS_STREAMS: the persistent Block
+        convolutions fill the chip in whole rounds with 8 + 8 utterances and leave nothing to overlap inside themselves; the
+        second stream overlaps the bandwidth-bound kernels in between)."""
         self._kw = dict(dim=dim, n_feats=n_feats, n_spks=n_spks, spk_emb_dim=spk_emb_dim, groups=groups,
                         pe_scale=pe_scale, beta_min=beta_min, beta_max=beta_max, precision=precision,
                         keep_intermediates=keep_intermediates, arch=arch, dim_cond=dim_cond, use_ref_t=use_ref_t,
@@ -197,7 +199,7 @@ class Plan:
         _check(lib().gtts_plan_create(ctypes.byref(self.cfg), ctypes.byref(self._h)), "gtts_plan_create")
         self._ws = {}
         if streams is None:
-            streams = int(os.environ.get("GTTS_STREAMS", "3"))
+            streams = int(os.environ.get("GTTS_STREAMS", "2"))
         self._nstreams = 0 if int(streams) < 2 else min(int(streams), 4)
         self._side = None           # (device, [torch.cuda.Stream])
         self._graph = False

@@ -29,9 +29,9 @@ print("rc", rc, "workgroups traced", a.shape[0], "(last traced launch of the cal
 c, p = a[:, :4], a[:, 4:]
 items = c[:, :, 3].mean()
 print("consumer: items %.0f  total %.0f cycles" % (items, c[:, :, 4].mean()))
-for i, n in enumerate(["barrier wait", "chunk loops", "tile epilogues"]):
-    print("  %-16s %10.0f  per item %8.0f  (%4.1f%%)" % (n, c[:, :, i].mean(), c[:, :, i].mean() / items, 100 * c[:, :, i].mean() / c[:, :, 4].mean()))
+for i, n in enumerate(["image wait", "chunk loops", "tile epilogues"]):
+    print("  %-16s %10.0f  per item %8.0f  (%4.1f%%)   per wave %s" % (n, c[:, :, i].mean(), c[:, :, i].mean() / items, 100 * c[:, :, i].mean() / c[:, :, 4].mean(), " ".join("%6.0f" % (c[:, w, i].mean() / items) for w in range(4))))
 print("producer: total %.0f cycles" % p[:, :, 4].mean())
-for i, n in enumerate(["barrier wait", "staging", "re-request", "finish_tile"]):
+for i, n in enumerate(["slot wait", "staging", "request setup", "finish_tile"]):
     print("  %-16s %10.0f  per item %8.0f  (%4.1f%%)" % (n, p[:, :, i].mean(), p[:, :, i].mean() / items, 100 * p[:, :, i].mean() / p[:, :, 4].mean()))
 print("  (first producer wave finish_tile: %.0f)" % p[:, 0, 3].mean())
