@@ -123,3 +123,53 @@ def test_shard_helpers():
         assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
     fb = D.shard_by_frames([100, 10, 10, 10, 100, 10], 2)
     assert fb[0][0] == 0 and fb[-1][1] == 6 and fb[0][1] == fb[1][0]
+
+
+def _bcast_worker(q):
+    """gtts_bcast_weights (the C ABI's RCCL entry point for non-torch hosts) carrying real bytes through a one-rank
+    ncclComm_t created with ctypes on the RCCL the process already has loaded."""
+    import ctypes
+    import sys
+    sys.path.insert(0, ROOT)
+    S = importlib.import_module("speech-backbones_amd")
+    dev = torch.device("cuda:0")
+    torch.zeros(1, device=dev)
+    path = None
+    for line in open("/proc/self/maps"):
+        if "librccl" in line:
+            path = line.split()[-1]
+            break
+    rccl = ctypes.CDLL(path or "librccl.so", mode=ctypes.RTLD_GLOBAL)
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    uid = UniqueId()
+    rccl.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    g = torch.Generator().manual_seed(0)
+    blob = torch.randint(0, 256, (3 * 1024 * 1024 + 17,), dtype=torch.uint8, generator=g).to(dev)
+    want = blob.clone()
+    L = S._lib.lib()
+    rc = L.gtts_bcast_weights(ctypes.c_void_p(blob.data_ptr()), blob.numel(), 0, comm, S._lib._stream())
+    torch.cuda.synchronize()
+    ok = rc == 0 and bool(torch.equal(blob, want))
+    err = L.gtts_last_error().decode() if rc else ""
+    rccl.ncclCommDestroy(comm)
+    q.put((ok, rc, err, path))
+
+
+@pytest.mark.gpu
+def test_bcast_weights_carries_bytes_through_rccl():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_bcast_worker, args=(q,))
+    p.start()
+    ok, rc, err, path = q.get(timeout=300)
+    p.join(timeout=60)
+    print("RCCL library:", path)
+    assert ok, (rc, err)

@@ -118,3 +118,144 @@ def test_vc_diffusion_module_drop_in(S, dev):
                                  "ml", noise=noise)
     assert relerr(out_ml, ref_ml) <= REL
     assert dec(a["z"], a["mask"], a["mean"], a["ref"], a["ref_mask"], a["mean_ref"], a["c"], 3, "bogus") is a["z"]
+
+
+def _vc_step_range(S, plan, blob, xt, a, N, mode, i0, i1, noise):
+    """Steps [i0, i1) of the N-step DiffVC sampler starting from state xt (through the C ABI's step ranges)."""
+    import ctypes
+    L = S._lib
+    B, F, T = xt.shape
+    Tr = int(a["ref_mask"].shape[-1])
+    out = xt.clone().contiguous()
+    ws = plan.vc_workspace(B, T, Tr, xt.device)
+    nz = noise.contiguous() if noise is not None else None
+    p = lambda v: ctypes.c_void_p(v.data_ptr()) if v is not None else None
+    rc = L.lib().gtts_vc_reverse_diffusion(plan._h, p(blob), p(xt), p(a["mask"]), p(a["mean"]), p(a["ref"]), p(a["ref_mask"]),
+                                           p(a["mean_ref"]), p(a["c"]), p(nz), p(out), p(ws), ws.numel(), B, T, Tr, N,
+                                           {"pf": 0, "em": 1, "ml": 2}[mode], i0, i1, L._stream())
+    assert rc == 0, L.lib().gtts_last_error()
+    torch.cuda.synchronize()
+    return out
+
+
+def _oracle_step(sd, xt, inp, N, mode, i, eps):
+    """One step of oracle/diffvc_oracle.py:reverse_diffusion (DiffVC/model/diffusion.py:168-195) from state xt."""
+    h = 1.0 / N
+    t = 1.0 - i * h
+    time = t * torch.ones(xt.shape[0])
+    beta_t, kappa, omega, sigma = V.step_coefficients(t, h, mode)
+    xt_ref = torch.stack([V.compute_diffused_mean(inp["ref"], inp["ref_mask"], inp["mean_ref"], t)], 1)
+    est = V.estimator_forward(sd, xt, inp["mask"], inp["mean"], xt_ref, inp["ref_mask"], inp["c"], time)
+    if mode == "pf":
+        dxt = 0.5 * (inp["mean"] - xt - est) * (beta_t * h)
+    else:
+        dxt = (inp["mean"] - xt) * (0.5 * beta_t * h + omega)
+        dxt -= est * (1.0 + kappa) * (beta_t * h)
+        dxt += eps * sigma
+    return (xt - dxt) * inp["mask"]
+
+
+def test_vc_ml_config4_n6_free_running_dim256(S, dev):
+    """BASELINE config 4 at its own N: the published decoder width (dim 256), fast maximum-likelihood sampler, N = 6, all six
+    steps free-running against the oracle (kappa / omega / sigma depend on N; the step times are computed on the device)."""
+    sd = V.make_state(dim_base=256, seed=6)
+    plan = S.Plan(dim=256, arch=1)
+    blob = plan.pack(sd, dev)
+    inp = V.make_inputs(1, 64, 32, seed=12)
+    g = torch.Generator().manual_seed(77)
+    noise = torch.randn(6, 1, 80, 64, generator=g)
+    ref = V.reverse_diffusion(sd, inp["z"], inp["mask"], inp["mean"], inp["ref"], inp["ref_mask"], inp["mean_ref"], inp["c"], 6, "ml",
+                              noise=noise)
+    a = {k: v.to(dev) for k, v in inp.items()}
+    out = plan.vc_reverse_diffusion(blob, a["z"], a["mask"], a["mean"], a["ref"], a["ref_mask"], a["mean_ref"], a["c"], 6, "ml",
+                                    noise=noise.to(dev)).cpu()
+    e = relerr(out, ref)
+    print("DiffVC ml N=6 dim256 free-running: rel err %.2e" % e)
+    assert e <= REL
+
+
+def test_vc_ml_n30_teacher_forced_steps_dim256(S, dev):
+    """N = 30 (what DiffVC/inference.ipynb runs), dim 256, T = 128: single steps early / middle / last of the schedule from
+    a given state against the oracle's step -- the 'ml' coefficients at N = 30 and the device-side step times."""
+    sd = V.make_state(dim_base=256, seed=6)
+    plan = S.Plan(dim=256, arch=1)
+    blob = plan.pack(sd, dev)
+    inp = V.make_inputs(1, 128, 40, seed=13)
+    a = {k: v.to(dev) for k, v in inp.items()}
+    g = torch.Generator().manual_seed(5)
+    for i in (0, 14, 29):
+        xt = (inp["mean"] + torch.randn(1, 80, 128, generator=g)) * inp["mask"]
+        eps = torch.randn(1, 80, 128, generator=g)
+        ref = _oracle_step(sd, xt, inp, 30, "ml", i, eps)
+        if i == 0:
+            out = _vc_step_range(S, plan, blob, xt.to(dev), a, 30, "ml", 0, 1, eps[None].to(dev)).cpu()
+        else:
+            out = _vc_step_range(S, plan, blob, xt.to(dev), a, 30, "ml", i, i + 1, eps[None].to(dev)).cpu()
+        e = relerr(out, ref)
+        print("DiffVC ml N=30 step %d: rel err %.2e" % (i, e))
+        assert e <= REL, "step %d" % i
+
+
+def test_vc_ml_n30_free_running_dim64(S, dev):
+    sd = V.make_state(dim_base=64, seed=3)
+    plan = S.Plan(dim=64, arch=1)
+    blob = plan.pack(sd, dev)
+    inp = V.make_inputs(2, 32, 24, seed=21)
+    g = torch.Generator().manual_seed(9)
+    noise = torch.randn(30, 2, 80, 32, generator=g)
+    ref = V.reverse_diffusion(sd, inp["z"], inp["mask"], inp["mean"], inp["ref"], inp["ref_mask"], inp["mean_ref"], inp["c"], 30,
+                              "ml", noise=noise)
+    a = {k: v.to(dev) for k, v in inp.items()}
+    out = plan.vc_reverse_diffusion(blob, a["z"], a["mask"], a["mean"], a["ref"], a["ref_mask"], a["mean_ref"], a["c"], 30, "ml",
+                                    noise=noise.to(dev)).cpu()
+    e = relerr(out, ref)
+    print("DiffVC ml N=30 dim64 free-running: rel err %.2e" % e)
+    assert e <= 2 * REL
+
+
+def test_diffvc_model_shell_drop_in(S, dev):
+    """`from model import DiffVC` (DiffVC/inference.ipynb): the whole model shell on the GPU -- MelEncoder, PostNet and the
+    decoder's sampler through the C ABI -- against the same composition of the CPU oracles."""
+    from oracle import encoder_oracle as E
+    from oracle import postnet_oracle as P
+    M = importlib.import_module("speech-backbones_amd.diffvc.model")
+    torch.manual_seed(1)
+    m = M.DiffVC(80, 64, 128, 2, 2, 3, 0.0, 4, 32, 128, True, 64, 0.05, 20.0).eval()
+    with torch.no_grad():
+        for n, prm in m.decoder.estimator.named_parameters():
+            if n.endswith("fn.g"):
+                prm.fill_(0.02)
+    msd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 80, 44, generator=g)
+    x_len = torch.tensor([44, 30])
+    x_ref = torch.randn(2, 80, 36, generator=g)
+    r_len = torch.tensor([36, 25])
+    c = torch.randn(2, 256, generator=g)
+    m = m.to(dev)
+    torch.manual_seed(123)
+    mean_x, y = m(x.to(dev), x_len.to(dev), x_ref.to(dev), r_len.to(dev), c.to(dev), 4, "ml")
+    # the same on the CPU oracles, drawing the same numbers in the same order on the same device
+    U = importlib.import_module("speech-backbones_amd.model.utils")
+    x_mask = U.sequence_mask(x_len).unsqueeze(1).float()
+    r_mask = U.sequence_mask(r_len).unsqueeze(1).float()
+    enc_sd = {k[len("encoder.encoder."):]: v for k, v in msd.items() if k.startswith("encoder.encoder.")}
+    post_sd = {k[len("encoder.postnet."):]: v for k, v in msd.items() if k.startswith("encoder.postnet.")}
+    dec_sd = {k[len("decoder.estimator."):]: v for k, v in msd.items() if k.startswith("decoder.estimator.")}
+
+    def avg_voice(v, mk):
+        return P.postnet_forward(post_sd, E.mel_encoder_forward(enc_sd, v, mk, n_heads=2, window=4, k=3), mk)
+
+    mean = avg_voice(x, x_mask)
+    mean_ref = avg_voice(x_ref, r_mask)
+    mean_x_ref = V.compute_diffused_mean(x, x_mask, mean, 1.0)
+    assert relerr(mean_x.cpu(), mean_x_ref) <= REL
+    keep = U.sequence_mask(x_len, 44).unsqueeze(1).float()
+    mask_pad = U.sequence_mask(x_len, 44).unsqueeze(1).float()
+    torch.manual_seed(123)
+    z = mean_x_ref * keep + torch.randn(2, 80, 44, device=dev).cpu()
+    noise = torch.stack([torch.randn(2, 80, 44, device=dev) for _ in range(4)]).cpu()
+    ref = V.reverse_diffusion(dec_sd, z, mask_pad, mean * keep, x_ref, r_mask, mean_ref, c, 4, "ml", noise=noise)
+    e = relerr(y.cpu(), ref)
+    print("DiffVC model shell: rel err %.2e" % e)
+    assert e <= 2 * REL

@@ -146,3 +146,53 @@ def test_estimator_parameter_gradients_match_cpu_autograd(S, dev):
     loss, _ = gpu.compute_loss(inp["z"].to(dev), inp["mask"].to(dev), inp["mu"].to(dev))
     loss.backward()
     assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in gpu.parameters())
+
+
+def test_gradtts_compute_loss_multispeaker_gpu_vs_cpu(S, dev):
+    """`GradTTS.compute_loss(..., spk=...)` as Grad-TTS/train_multi_speaker.py:105-120 calls it (speaker embedding -> encoder
+    and decoder condition, MAS on the device's own scores, random crop off): the three losses and a gradient sample on the GPU
+    (HIP training kernels) against the same module on the CPU (the composition test_model_cpu.py pins to the reference)."""
+    M = importlib.import_module("speech-backbones_amd.model")
+    torch.manual_seed(3)
+    cpu = M.GradTTS(149, 5, 64, 192, 768, 256, 2, 6, 3, 0.1, 4, 80, 64, 0.05, 20.0, 1000)
+    with torch.no_grad():
+        for n, prm in cpu.decoder.estimator.named_parameters():
+            if n.endswith("fn.g"):
+                prm.fill_(0.3)
+    gpu = copy.deepcopy(cpu).to(dev)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randint(0, 149, (2, 17), generator=g)
+    xl = torch.tensor([17, 11])
+    y = torch.randn(2, 80, 64, generator=g)
+    yl = torch.tensor([64, 48])
+    spk = torch.tensor([1, 4])
+    # the time draw of Diffusion.compute_loss and the noise draw of forward_diffusion come from the device's generator:
+    # draw them once on the CPU and replay them on both sides
+    t_fix = torch.tensor([0.37, 0.71])
+    z_fix = torch.randn(2, 80, 64, generator=g)
+    D = importlib.import_module("speech-backbones_amd.model.diffusion")
+    losses = {}
+    for tag, m, d in (("cpu", cpu, torch.device("cpu")), ("gpu", gpu, dev)):
+        orig_rand, orig_randn = torch.rand, torch.randn
+        torch.rand = lambda *a, **k: t_fix.to(k.get("device", "cpu"))
+        torch.randn = lambda *a, **k: z_fix.to(k.get("device", "cpu"))
+        try:
+            losses[tag] = m.compute_loss(x.to(d), xl.to(d), y.to(d), yl.to(d), spk=spk.to(d), out_size=None)
+        finally:
+            torch.rand, torch.randn = orig_rand, orig_randn
+        sum(losses[tag]).backward()
+    for a, b, name in zip(losses["cpu"], losses["gpu"], ("duration", "prior", "diffusion")):
+        assert abs(float(a) - float(b)) <= 2e-4 * abs(float(a)) + 1e-6, (name, float(a), float(b))
+    worst = ("", 0.0)
+    pc = dict(cpu.named_parameters())
+    for name, p in gpu.named_parameters():
+        if p.grad is None or pc[name].grad is None:
+            assert (p.grad is None) == (pc[name].grad is None), name
+            continue
+        e = relerr(p.grad.cpu(), pc[name].grad)
+        if p.numel() == 1:
+            e = e / 5.0
+        worst = max(worst, (name, e), key=lambda kv: kv[1])
+    print("GradTTS(5 speakers).compute_loss: worst gradient rel err %.2e (%s)" % worst[::-1])
+    assert worst[1] <= 5e-4, worst
+    assert gpu.spk_emb.weight.grad is not None and float(gpu.spk_emb.weight.grad.abs().max()) > 0
