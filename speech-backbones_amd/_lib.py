@@ -185,9 +185,10 @@ class Plan:
         """arch=0: Grad-TTS GradLogPEstimator2d; arch=1: DiffVC GradLogPEstimator (dim = dim_base).
 
         streams: number of sub-batches gtts_reverse_diffusion runs side by side on torch side streams owned by this
-        object and registered with gtts_plan_set_streams (0 / 1: no split; default 2, or $GTTS_STREAMS: the persistent Block
-        convolutions fill the chip in whole rounds with 8 + 8 utterances and leave nothing to overlap inside themselves; the
-        second stream overlaps the bandwidth-bound kernels in between)."""
+        object and registered with gtts_plan_set_streams (0 / 1: no split; $GTTS_STREAMS overrides the default).  Default 2 for
+        bf16x3: the persistent Block convolutions fill the chip in whole rounds with 8 + 8 utterances and leave nothing to
+        overlap inside themselves, the second stream overlaps the bandwidth-bound kernels in between.  Default 3 for the
+        single-pass bf16 modes, whose convolutions are conv_mfma.hip's and overlap well."""
         self._kw = dict(dim=dim, n_feats=n_feats, n_spks=n_spks, spk_emb_dim=spk_emb_dim, groups=groups,
                         pe_scale=pe_scale, beta_min=beta_min, beta_max=beta_max, precision=precision,
                         keep_intermediates=keep_intermediates, arch=arch, dim_cond=dim_cond, use_ref_t=use_ref_t,
@@ -199,7 +200,7 @@ class Plan:
         _check(lib().gtts_plan_create(ctypes.byref(self.cfg), ctypes.byref(self._h)), "gtts_plan_create")
         self._ws = {}
         if streams is None:
-            streams = int(os.environ.get("GTTS_STREAMS", "2"))
+            streams = int(os.environ.get("GTTS_STREAMS", "2" if int(precision) == PREC_BF16X3 else "3"))
         self._nstreams = 0 if int(streams) < 2 else min(int(streams), 4)
         self._side = None           # (device, [torch.cuda.Stream])
         self._graph = False
@@ -461,6 +462,9 @@ class Plan:
 
     # ---- debugging: named intermediates (keep_intermediates plans)
     def tensors(self, B, T, device):
+        if int(self.cfg.precision) == PREC_BF16_STORE:
+            raise RuntimeError("Plan.tensors(): the named-intermediate views are fp32; a keep_intermediates plan with bf16 "
+                               "activation storage stores 2-byte activations -- use PREC_BF16 / PREC_BF16X3 for tap tests")
         L = lib()
         ws = self.workspace(B, T, device)
         out = {}
@@ -498,8 +502,12 @@ class Vocoder:
         for k, (u, ks) in enumerate(zip(upsample_rates, upsample_kernel_sizes)):
             cfg.upsample_rates[k] = int(u)
             cfg.upsample_kernel_sizes[k] = int(ks)
+        want = 3 if str(resblock) == "1" else 2       # ResBlock1 walks three dilations, ResBlock2 two (models.py:11-74)
         for k, (ks, dil) in enumerate(zip(resblock_kernel_sizes, resblock_dilation_sizes)):
             cfg.resblock_kernel_sizes[k] = int(ks)
+            if len(dil) != want:
+                raise RuntimeError("resblock_dilation_sizes[%d] has %d entries; the HIP ResBlock%s runs exactly %d (the torch "
+                                   "module would accept any count, the kernel does not)" % (k, len(dil), resblock, want))
             for j in range(3):
                 cfg.resblock_dilations[k][j] = int(dil[j]) if j < len(dil) else 1
         self.cfg = cfg
@@ -798,14 +806,40 @@ def conv3x3_supported(cin, cout):
     return cin % 32 == 0 and cout % 32 == 0 and tiles(cin) and tiles(cout)
 
 
+_PACKED = {}       # (device, weight storage, weight version, transposed) -> packed blob; an optimizer step bumps the version
+_CONSTS = {}       # (device, kind, n) -> ones / zeros of the data-gradient call
+
+
+def _packed_conv3x3(weight, cin, cout, transposed):
+    key = (str(weight.device), weight.data_ptr(), int(weight._version), bool(transposed), cin, cout)
+    hit = _PACKED.get(key)
+    if hit is not None:
+        return hit
+    L = lib()
+    packed = torch.empty(int(L.gtts_conv3x3_packed_bytes(cin, cout)), dtype=torch.uint8, device=weight.device)
+    _check(L.gtts_conv3x3_pack(_ptr(weight), _ptr(packed), cin, cout, 1 if transposed else 0, _stream()), "gtts_conv3x3_pack")
+    if len(_PACKED) >= 256:          # (two entries per Block convolution: 50 for the Grad-TTS U-Net)
+        _PACKED.clear()
+    _PACKED[key] = packed
+    return packed
+
+
+def _const(device, kind, *shape):
+    key = (str(device), kind) + shape
+    v = _CONSTS.get(key)
+    if v is None:
+        v = (torch.ones if kind == "ones" else torch.zeros)(shape, dtype=torch.float32, device=device)
+        _CONSTS[key] = v
+    return v
+
+
 def _conv3x3_run(x, mask_cols, weight, bias, transposed):
     B, cin, H, W = x.shape
     cout = weight.shape[1] if transposed else weight.shape[0]
     L = lib()
-    packed = torch.empty(int(L.gtts_conv3x3_packed_bytes(cin, cout)), dtype=torch.uint8, device=x.device)
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _check(L.gtts_conv3x3_pack(_ptr(weight), _ptr(packed), cin, cout, 1 if transposed else 0, _stream()), "gtts_conv3x3_pack")
+        packed = _packed_conv3x3(weight, cin, cout, transposed)
         _check(L.gtts_conv3x3_masked(_ptr(x), _ptr(mask_cols), _ptr(packed), _ptr(bias), _ptr(y), B, cin, cout, H, W, _stream()),
                "gtts_conv3x3_masked")
     return y
@@ -821,9 +855,7 @@ def conv3x3_dgrad(dy, weight):
     """Gradient of conv3x3_masked w.r.t. (x * mask): a 3x3 convolution of dy with the transposed, flipped weights."""
     dy, weight = _f32c(dy, "dy"), _f32c(weight, "weight")
     B, cout, H, W = dy.shape
-    ones = torch.ones((B, W), dtype=torch.float32, device=dy.device)
-    zero = torch.zeros(weight.shape[1], dtype=torch.float32, device=dy.device)
-    return _conv3x3_run(dy, ones, weight, zero, True)
+    return _conv3x3_run(dy, _const(dy.device, "ones", B, W), weight, _const(dy.device, "zeros", int(weight.shape[1])), True)
 
 
 def conv3x3_wgrad(x, mask_cols, dy):
@@ -884,7 +916,12 @@ def diffusion_noising(x0, mu, z, mask, t, beta_min, beta_max):
 
 
 def score_loss(eps, z_masked, t, beta_min, beta_max, inv_denom, want_grad=True):
-    """Diffusion.loss_t's reduction: (sum((eps s + z)^2) * inv_denom as a 0-d tensor, d loss / d eps or None)."""
+    """Diffusion.loss_t's reduction: (sum((eps s + z)^2) * inv_denom as a 0-d tensor, d loss / d eps or None).
+    inv_denom: a Python float, or a 0-d device tensor (then nothing here synchronises with the host: the kernel runs with a
+    unit normaliser and loss and gradient are scaled by tensor ops)."""
+    if torch.is_tensor(inv_denom):
+        loss, g = score_loss(eps, z_masked, t, beta_min, beta_max, 1.0, want_grad)
+        return loss * inv_denom, (g * inv_denom if g is not None else None)
     eps, z_masked, t = _f32c(eps, "eps"), _f32c(z_masked, "z"), _f32c(t, "t")
     B, F, T = eps.shape
     n = int(lib().gtts_score_loss_partials(B, F, T))

@@ -27,6 +27,23 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// Fused GroupNorm finalize hand-off (conv_mfma.hip, conv_ws.hip).  What the product build relies on, instruction by instruction
+// (gfx950, ROCm 7.2; MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility"):
+//   * the partial sums are stored with relaxed agent-scope atomic stores = `global_store_dword ... sc1`: write-through, the
+//     line leaves this XCD's L2 towards memory instead of waiting dirty in it;
+//   * `s_waitcnt vmcnt(0)` in inline asm (the compiler can neither drop nor move it) retires those stores before the wave
+//     draws its ticket: relaxed agent-scope `global_atomic_add` with return, performed at the memory side;
+//   * the workgroup that draws the last ticket of a sample reads every partial with relaxed agent-scope atomic loads =
+//     `global_load ... sc1`: they bypass the CU's L1, and L2 cannot hold a stale copy of a line nobody on this XCD has read.
+// This is the guide's "sc1 payload -> asm vmcnt(0) -> flag" form with the ticket as the flag; it is NOT the C++ memory model's
+// release / acquire pair (a relaxed RMW orders nothing formally), which on gfx950 is `buffer_wbl2 sc1` (+15...50 % on every
+// convolution: it writes back all dirty output lines of the XCD) and `buffer_inv sc1`.  -DGTTS_FENCED_FINALIZE=1 builds add
+// exactly those two fences: the reference variant for A/B runs and for a compiler / chip on which the assumption breaks
+// (tools/gpu_fenced_check.sh compares the two builds bit for bit).
+#ifndef GTTS_FENCED_FINALIZE
+#define GTTS_FENCED_FINALIZE 0
+#endif
+
 // Linear workgroup id -> position in an XCD-banded order: id % 8 is the XCD the hardware picks, id / 8 the order of
 // arrival there.  Bijective for any n (the first n % 8 bands are one longer).  GTTS_XCD_BANDS=0 keeps the identity.
 #ifndef GTTS_XCD_BANDS
@@ -210,8 +227,9 @@ hipError_t launch_conv(int mode, const ConvArgs &a, hipStream_t st);
 #ifndef GTTS_WS
 #define GTTS_WS 1
 #endif
-bool conv_ws_eligible(int mode, int c0, int c1, int cout, int pro, int epi);
-int conv_ws_nparts(int cout, int Hout, int Wout);      // GroupNorm partial slots per sample it writes (one per pixel tile)
+bool conv_ws_eligible(int mode, int c0, int c1, int cout, int pro, int epi, int nsplit);
+int conv_ws_nparts(int cout, int Hout, int Wout);      // GroupNorm partial slots per sample it writes (one per 32-frame x 5-row block)
+bool conv_ws_small(int cout, int Hout, int Wout, int B);   // the launch takes the two-wave workgroup form (same arithmetic)
 hipError_t launch_conv_ws(const ConvArgs &a, hipStream_t st);
 bool conv_small_tiles(int mode, int cout, int Hout, int Wout, int B);   // half-height tiles for launches smaller than the chip
 bool conv_rowpair_stats(int mode, int cout, int Hout, int Wout);        // GroupNorm partial slots per row pair (batch-size independent)

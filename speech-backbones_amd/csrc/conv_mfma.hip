@@ -796,12 +796,18 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
         // with sc1 loads and reduces them in a fixed order (fp64), so the result does not depend on which workgroup happens
         // to be last.
         if (a.ticket != nullptr && wave == 0) {
+#if GTTS_FENCED_FINALIZE
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // the textbook form (see common.h): buffer_wbl2 sc1
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             unsigned old = 0;
             if (lane == 0) old = __hip_atomic_fetch_add(a.ticket + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             old = __builtin_amdgcn_readfirstlane(old);
             const unsigned total = (unsigned)(a.tiles_x * a.tiles_y * ncot);
             if (old == total - 1) {
+#if GTTS_FENCED_FINALIZE
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
                 // This tail is serial (the last workgroup of the last sample runs it alone), so it is organised for few
                 // dependent memory round trips: 16 lanes walk the slots of a PAIR of groups, two 8-byte sc1 loads per slot
                 // and eight slots in flight per lane; then 8 lanes per group finish.  Fixed order: deterministic.
@@ -976,7 +982,7 @@ static hipError_t launch_prec(const ConvArgs &a, hipStream_t st) {
 hipError_t launch_conv(int mode, const ConvArgs &a, hipStream_t st) {
     const bool wide = a.cout > 64;
     // Block convolutions on whole 16-channel chunks: the persistent wave-specialised kernel (conv_ws.hip)
-    if (conv_ws_eligible(mode, a.c0, a.c1, a.cout, a.pro, a.epi)) return launch_conv_ws(a, st);
+    if (conv_ws_eligible(mode, a.c0, a.c1, a.cout, a.pro, a.epi, a.nsplit)) return launch_conv_ws(a, st);
     switch (mode) {
         case CONV_C3:
             if (a.epi == EPI_PLAIN) {          // DiffVC RefBlock convolutions (InstanceNorm statistics are a separate pass)

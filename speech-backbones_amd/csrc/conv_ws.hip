@@ -64,39 +64,41 @@ namespace gtts {
 
 template <int WM, int WN, int MF, int NF>
 struct WsCfg {
+    static constexpr int NCW = WM * WN;          // consumer waves (= producer waves): 4, or 1 in the small-launch form
+    static constexpr int NT = 2 * NCW * 64;      // threads per workgroup
     static constexpr int MT = WM * MF * 32;      // output channels per workgroup
     static constexpr int TR = WN * NF;           // output rows per workgroup
     static constexpr int HR = TR + 2, HC = 34;   // halo tile
     static constexpr int NPIX = HR * HC;
     static constexpr int NKG = 2;                // 8-channel groups per 16-channel chunk
-    static constexpr int NITEM = NKG * NPIX;     // (pixel, 8-channel group) staging items per chunk
-    static constexpr int AITER = (NITEM + 255) / 256;
-    static_assert(WM * WN == 4, "four consumer waves");
+    static_assert(NCW == 4 || NCW == 1, "four consumer waves, or one");
 };
 
-static inline size_t ws_smem_bytes(int npix, int nsplit, int ring, int cin, int pro, int mt, int mf) {
+static inline size_t ws_smem_bytes(int npix, int nsplit, int ring, int cin, int pro, int mt, int mf, int ncw) {
     const size_t cpad = (size_t)((cin + 15) / 16) * 16;
-    return (size_t)ring * nsplit * 2 * npix * 16 + (pro == PRO_GN ? (size_t)2 * 3 * cpad * 4 : 0) + (size_t)2 * 4 * mf * 8 * 4 +
+    return (size_t)ring * nsplit * 2 * npix * 16 + (pro == PRO_GN ? (size_t)2 * 3 * cpad * 4 : 0) + (size_t)2 * ncw * mf * 8 * 4 +
            (size_t)2 * mt * 4;
 }
 
 template <int WM, int WN, int MF, int NF, int PRO, int NSPLIT, typename AT, int RING>
-__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 128, 2) void conv3x3_ws_kernel(const ConvArgs a) {
     using C = WsCfg<WM, WN, MF, NF>;
     constexpr int AB = (int)sizeof(AT);
-    constexpr int MT = C::MT, TR = C::TR, HC = C::HC, NPIX = C::NPIX, NKG = C::NKG, AITER = C::AITER;
+    constexpr int MT = C::MT, TR = C::TR, HC = C::HC, NPIX = C::NPIX, NKG = C::NKG, NCW = C::NCW, NPT = NCW * 64;
     constexpr int PLANE16 = NKG * NPIX;              // 16-byte units of one plane (hi or lo) of an image
     constexpr int IMG16 = NSPLIT * PLANE16;          // ... of one ring slot
     constexpr int D = RING - 1;                      // producers run D chunks ahead
-    constexpr int WBLK16 = 3 * MT * 2 * NKG;         // packed weight block (chunk, stage, cout tile): [split][tap][kg][MT] x 16 B
+    // packed weight block (chunk, stage, cout tile of the PACKING: 128 channels for cout > 64): [split][tap][kg][MTP] x 16 B
+    const int MTP = a.cout > 64 ? 128 : 64;
+    const int WBLK16 = 3 * MTP * 2 * NKG;
     static_assert(PRO == PRO_MASK || PRO == PRO_GN, "Block prologues only");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4 *s_img = reinterpret_cast<u32x4 *>(smem);                      // [RING][split][kg][NPIX]
     const int cpad = a.nchunk * 16;
     float *s_par = reinterpret_cast<float *>(s_img + RING * IMG16);      // PRO_GN: [2 (tile parity)][3][cpad] scale, shift, time bias
-    float *s_red = s_par + (PRO == PRO_GN ? 2 * 3 * cpad : 0);           // [2 (tile parity)][4 waves][MF][4 octets][2]
-    float *s_epi = s_red + 2 * 4 * MF * 8;                               // [2 (tile parity)][MT] bias
+    float *s_red = s_par + (PRO == PRO_GN ? 2 * 3 * cpad : 0);           // [2 (tile parity)][NCW waves][MF][4 octets][2]
+    float *s_epi = s_red + 2 * NCW * MF * 8;                             // [2 (tile parity)][MT] bias
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -138,23 +140,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs a) {
     unsigned long long tr_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long tr_entry = WT_NOW();
 #endif
-    if (wave < 4) {
+    if (wave < NCW) {
         // =================================================================================== CONSUMERS
         __builtin_amdgcn_s_setprio(3);         // MFMA issue wins the per-SIMD arbitration against the producers' VALU stream
         const int wm = wave / WN, wn = wave % WN;
         const int m0 = wm * MF * 32;
-        const int wtotal = nchunk * 3 * ncot * WBLK16 * 16;
+        const int ncotp = a.cout / MTP, cpp = MTP / MT;             // packing tiles; workgroup cout tiles per packing tile
+        const int wtotal = nchunk * 3 * ncotp * WBLK16 * 16;
         const __amdgpu_buffer_rsrc_t rsw = uniform_rsrc(a.w, wtotal);
-        const int w_voff = (kg_l * MT + m0 + l31) * 16;             // lane's row inside a (split, tap, kg) segment
+        const int w_lane = (kg_l * MTP + m0 + l31) * 16;            // lane's row inside a (split, tap, kg) segment of the packing tile
         // A fragments of (chunk, stage, tap) of cout tile cot: hi [mi], lo [MF + mi]
         auto wload = [&](bf16x8 (&w)[MF * NSPLIT], int chunk, int stage, int tap, int cot) {
-            const int blk = (chunk * 3 + stage) * ncot + cot;
+            const int blk = (chunk * 3 + stage) * ncotp + cot / cpp;
+            const int w_voff = w_lane + (cot % cpp) * MT * 16;
 #pragma unroll
             for (int sp = 0; sp < NSPLIT; ++sp)
 #pragma unroll
                 for (int mi = 0; mi < MF; ++mi) {
                     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
-                        rsw, w_voff + mi * 32 * 16, blk * (WBLK16 * 16) + ((sp * 3 + tap) * NKG * MT) * 16, 0);
+                        rsw, w_voff + mi * 32 * 16, blk * (WBLK16 * 16) + ((sp * 3 + tap) * NKG * MTP) * 16, 0);
                     w[sp * MF + mi] = __builtin_bit_cast(bf16x8, v);
                 }
         };
@@ -171,18 +175,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs a) {
         const int x_lane = kg_l * NPIX + wn * NF * HC + l31;
         auto wload_one = [&](bf16x8 (&w)[MF], int mi, int sp, int chunk, int stage, int tap, int cot) {
             if (GTTS_WS_EXP == 1 && (chunk | stage | tap) != 0) return;
-            const int blk = (chunk * 3 + stage) * ncot + cot;
+            const int blk = (chunk * 3 + stage) * ncotp + cot / cpp;
+            const int w_voff = w_lane + (cot % cpp) * MT * 16;
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
-                rsw, w_voff + mi * 32 * 16, blk * (WBLK16 * 16) + ((sp * 3 + tap) * NKG * MT) * 16, 0);
+                rsw, w_voff + mi * 32 * 16, blk * (WBLK16 * 16) + ((sp * 3 + tap) * NKG * MTP) * 16, 0);
             w[mi] = __builtin_bit_cast(bf16x8, v);
         };
         auto wload1 = [&](bf16x8 (&w)[MF], int sp, int chunk, int stage, int tap, int cot) {
             if (GTTS_WS_EXP == 1 && (chunk | stage | tap) != 0) return;
-            const int blk = (chunk * 3 + stage) * ncot + cot;
+            const int blk = (chunk * 3 + stage) * ncotp + cot / cpp;
+            const int w_voff = w_lane + (cot % cpp) * MT * 16;
 #pragma unroll
             for (int mi = 0; mi < MF; ++mi) {
                 const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
-                    rsw, w_voff + mi * 32 * 16, blk * (WBLK16 * 16) + ((sp * 3 + tap) * NKG * MT) * 16, 0);
+                    rsw, w_voff + mi * 32 * 16, blk * (WBLK16 * 16) + ((sp * 3 + tap) * NKG * MTP) * 16, 0);
                 w[mi] = __builtin_bit_cast(bf16x8, v);
             }
         };
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs a) {
                     for (int ni = 0; ni < NF; ++ni)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-                if (tid < MT) s_epi[par * MT + tid] = a.bias[tl.cot * MT + tid];
+                for (int c = tid; c < MT; c += NPT) s_epi[par * MT + c] = a.bias[tl.cot * MT + c];
             } else if (RING < 3) {
 #pragma unroll
                 for (int ni = 0; ni < NF; ++ni) xh[ni] = *reinterpret_cast<const bf16x8 *>(xh_p + ni * HC);
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs a) {
                     for (int kk = 0; kk < V / 4; ++kk) {
                         const int vi = kk + (V / 4) * (r & 1) + (V / 2) * (r >> 1);
                         const int which = vi / (4 * MF), mi = (vi % (4 * MF)) >> 2, q = vi & 3;
-                        s_red[par * (4 * MF * 8) + ((wave * MF + mi) * 4 + q) * 2 + which] = tot[kk];
+                        s_red[par * (NCW * MF * 8) + ((wave * MF + mi) * 4 + q) * 2 + which] = tot[kk];
                     }
                 }
             }
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs a) {
         lds_barrier();                                              // (F) the last tile's wave sums are in s_red
     } else {
         // =================================================================================== PRODUCERS
-        const int ptid = tid - 256;
+        const int ptid = tid - NPT;
         // A staging item is (8-channel group, halo row, GROUP OF FOUR consecutive frames): eight 16-byte loads (one per
         // channel; 8 bytes in bf16 storage) instead of thirty-two dword loads -- the texture path spends its address cycles
         // per instruction, and with dword loads the producers' requests alone kept it busy for a third of a chunk, in front of
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs a) {
         // straddles the image edge reads the neighbouring row's frames (valid memory) and the mask factor zeroes them.
         constexpr int NG = 9;                         // frame groups per halo row
         constexpr int NLI = NKG * C::HR * NG;         // lane-items per chunk
-        constexpr int LITER = (NLI + 255) / 256;
+        constexpr int LITER = (NLI + NPT - 1) / NPT;
         typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
         using RawV = typename std::conditional<AB == 4, u32x4, u32x2>::type;
         struct Raw { RawV x[LITER][8]; };
@@ -387,7 +393,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs a) {
             const int iy0 = t.ty * TR - 1, ix0 = t.tx * 32 - 1;
 #pragma unroll
             for (int it = 0; it < LITER; ++it) {
-                const int idx = ptid + it * 256;
+                const int idx = ptid + it * NPT;
                 const bool has = idx < NLI;
                 const int kg = min(idx / (C::HR * NG), NKG - 1);
                 const int rem = idx - (idx / (C::HR * NG)) * (C::HR * NG);
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs a) {
         auto write_params = [&](const TileId &t, int par) {
             if constexpr (PRO == PRO_GN) {
                 float *sp = s_par + par * 3 * cpad;
-                for (int i = ptid; i < cpad; i += 256) {
+                for (int i = ptid; i < cpad; i += NPT) {
                     sp[i] = a.sc[(size_t)t.b * a.cin + i];
                     sp[cpad + i] = a.sh[(size_t)t.b * a.cin + i];
                     sp[2 * cpad + i] = a.tb ? a.tb[(size_t)t.b * a.tb_stride + i] : 0.f;
@@ -453,7 +459,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs a) {
             const float *sp = s_par + par * 3 * cpad;
 #pragma unroll
             for (int it = 0; it < LITER; ++it) {
-                const int idx = ptid + it * 256;
+                const int idx = ptid + it * NPT;
                 const bool has = idx < NLI;
                 const int kg = min(idx / (C::HR * NG), NKG - 1);
                 const int rem = idx - (idx / (C::HR * NG)) * (C::HR * NG);
@@ -533,27 +539,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs a) {
         // GroupNorm partial sums of a finished tile (the consumers' wave sums are in s_red[par]) + fused finalize; first
         // producer wave only.  Slot = pixel tile; value order: octets of the group, then the WN wave rows -- fixed.
         auto finish_tile = [&](const TileId &t, int par) {
+            // One partial slot per (32-frame column block, 5-row band) = per consumer wave row: the slot's value is formed by ONE
+            // wave's sums, so the workgroup shape (four consumer waves, or one in the small-launch form) cannot change it.
             const int gs = a.cout / a.groups;
             const int gpw = MT / gs > 0 ? MT / gs : 1;
-            const float *red = s_red + par * (4 * MF * 8);
-            if (lane < gpw) {
-                const int g = (t.cot * MT) / gs + lane;
+            const float *red = s_red + par * (NCW * MF * 8);
+            if (lane < gpw * WN) {
+                const int gl = lane % gpw, wc = lane / gpw;
+                const int g = (t.cot * MT) / gs + gl;
                 if (g < a.groups) {
-                    const int noct = (gs < MT ? gs : MT) >> 3, o0 = lane * noct;
+                    const int noct = (gs < MT ? gs : MT) >> 3, o0 = gl * noct;
                     float s1 = 0.f, s2 = 0.f;
                     for (int o = o0; o < o0 + noct; ++o) {
                         const int f = o >> 2, q = o & 3, wmm = f / MF, mi = f - wmm * MF;
-#pragma unroll
-                        for (int wc = 0; wc < WN; ++wc) {
-                            const int w = wmm * WN + wc;
-                            s1 += red[((w * MF + mi) * 4 + q) * 2 + 0];
-                            s2 += red[((w * MF + mi) * 4 + q) * 2 + 1];
-                        }
+                        const int w = wmm * WN + wc;
+                        s1 += red[((w * MF + mi) * 4 + q) * 2 + 0];
+                        s2 += red[((w * MF + mi) * 4 + q) * 2 + 1];
                     }
-                    const int pslot = t.tx * a.tiles_y + t.ty;
+                    const int pslot = t.tx * (a.tiles_y * WN) + t.ty * WN + wc;
                     float *p = a.partials + (((size_t)t.b * a.nparts + pslot) * a.groups + g) * 2;
                     if (a.ticket != nullptr) {
-                        // write-through (sc1) stores + vmcnt drain + relaxed agent-scope ticket: see conv_mfma.hip (the agent-scope
+                        // write-through (sc1) stores + vmcnt drain + relaxed agent-scope ticket: see common.h (the agent-scope
                         // release would write back every dirty output line of this XCD's L2)
                         __hip_atomic_store(p, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(p + 1, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -564,11 +570,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs a) {
                 }
             }
             if (a.ticket == nullptr) return;
+#if GTTS_FENCED_FINALIZE
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // the textbook form (see common.h): buffer_wbl2 sc1
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             unsigned old = 0;
             if (lane == 0) old = __hip_atomic_fetch_add(a.ticket + t.b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             old = __builtin_amdgcn_readfirstlane(old);
             if (old != (unsigned)(tps * ncot) - 1) return;
+#if GTTS_FENCED_FINALIZE
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
             // last tile of the sample: fixed-order fp64 reduction of ALL partials of the sample (sc1 loads), 8 lanes per group
             const int b = t.b;
             const int g = lane >> 3, sub = lane & 7;
@@ -627,7 +639,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs a) {
             WT_ADD(1, WT_NOW(), t1);
         };
         auto fin = [&](int i) {       // consumer item i - 1 closed a tile: its wave sums were written before this barrier
-            if (wave == 4 && i > 0 && i % nchunk == 0) {
+            if (wave == NCW && i > 0 && i % nchunk == 0) {
                 const int kt = i / nchunk - 1;
                 finish_tile(decode(kt), kt & 1);
             }
@@ -662,7 +674,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs a) {
             }
         }
         lds_barrier();                                 // (F)
-        if (wave == 4 && nitems > 0) finish_tile(decode(my_tiles - 1), (my_tiles - 1) & 1);
+        if (wave == NCW && nitems > 0) finish_tile(decode(my_tiles - 1), (my_tiles - 1) & 1);
     }
 #if GTTS_WS_TRACE
     if (tr_on && lane == 0 && (blockIdx.x >> 2) < 64) {
@@ -674,33 +686,47 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs a) {
 
 // ---------------------------------------------------------------------------------------------------- host side
 // Which Block convolutions take this kernel: 3x3, whole 16-channel chunks (a concatenated input splitting on a chunk
-// boundary), mask / GroupNorm prologue, statistics epilogue, at least 32 input channels, whole cout tiles.
-bool conv_ws_eligible(int mode, int c0, int c1, int cout, int pro, int epi) {
+// boundary), mask / GroupNorm prologue, statistics epilogue, at least 32 input channels, whole cout tiles -- and the
+// fp32-grade bf16x3 precision: the single-pass bf16 modes (BASELINE config 3) have a third of the MFMA work per staged value,
+// the four producer waves cannot keep up with the consumers there, and conv_mfma.hip's uniform waves on three sub-batch
+// streams are faster (measured: 5.9 vs 3.7 ms per U-Net call).
+bool conv_ws_eligible(int mode, int c0, int c1, int cout, int pro, int epi, int nsplit) {
     const int cin = c0 + c1;
-    if (!GTTS_WS) return false;
+    if (!GTTS_WS || nsplit != 2) return false;
     if (mode != CONV_C3 || epi != EPI_STATS || (pro != PRO_MASK && pro != PRO_GN)) return false;
     if (cin % 16 != 0 || cin < 32 || (c1 != 0 && c0 % 16 != 0)) return false;
-    return cout % 64 == 0 && (cout <= 64 || cout % 128 == 0);
+    if (!(cout % 64 == 0 && (cout <= 64 || cout % 128 == 0))) return false;
+    // three activation images + the per-channel parameters must fit the CU's LDS
+    const int npix = (cout <= 64 ? 22 : 12) * 34;
+    return ws_smem_bytes(npix, 2, 3, cin, pro, cout <= 64 ? 64 : 128, 2, 4) <= (size_t)160 * 1024;
 }
-// tile geometry of a layer (a function of the layer only, never of the batch)
-static inline void ws_tile(int cout, int *mt, int *tr) {
-    *mt = cout <= 64 ? 64 : 128;
-    *tr = cout <= 64 ? 20 : 10;
-}
+// GroupNorm partial slots per sample: one per (32-frame column block, 5-row band), whatever the workgroup shape
 int conv_ws_nparts(int cout, int Hout, int Wout) {
-    int mt, tr;
-    ws_tile(cout, &mt, &tr);
-    return ((Wout + 31) / 32) * ((Hout + tr - 1) / tr);
+    (void)cout;
+    return ((Wout + 31) / 32) * ((Hout + 4) / 5);
+}
+// A launch whose regular tiling (128 channels x 10 rows, or 64 x 20) gives fewer workgroups than this takes the small form:
+// one consumer + one producer wave per workgroup on a 64-channel x 5-row tile -- the SAME wave tile, so every output and
+// every partial sum is bit-identical and results do not depend on the batch size.
+#ifndef GTTS_WS_SMALL_WGS
+#define GTTS_WS_SMALL_WGS 160
+#endif
+bool conv_ws_small(int cout, int Hout, int Wout, int B) {
+    const int mt = cout <= 64 ? 64 : 128, tr = cout <= 64 ? 20 : 10;
+    const long wgs = (long)B * ((Wout + 31) / 32) * ((Hout + tr - 1) / tr) * (cout / mt);
+    return wgs < GTTS_WS_SMALL_WGS;
 }
 
-template <int WM, int WN, int MF, int NF, int PRO, int NSPLIT, typename AT>
+template <int WM, int WN, int PRO, int NSPLIT, typename AT>
 static hipError_t launch_ws_ring(ConvArgs &a, hipStream_t st) {
+    constexpr int MF = 2, NF = 5;
     using C = WsCfg<WM, WN, MF, NF>;
     a.nchunk = a.cin / 16;
     a.tiles_x = (a.Wout + 31) / 32;
     a.tiles_y = (a.Hout + C::TR - 1) / C::TR;
-    a.nparts = a.tiles_x * a.tiles_y;
+    a.nparts = a.tiles_x * a.tiles_y * WN;
     a.stat_rows = 0;
+    if (a.nparts != conv_ws_nparts(a.cout, a.Hout, a.Wout)) return hipErrorInvalidValue;      // (H % 5 rows of slack would differ)
     const size_t lim = (size_t)1 << 31;
     if ((size_t)std::max(a.c0, a.c1) * a.Hin * a.Win * sizeof(AT) >= lim || (size_t)a.cout * a.Hout * a.Wout * sizeof(AT) >= lim)
         return hipErrorInvalidValue;
@@ -712,45 +738,39 @@ static hipError_t launch_ws_ring(ConvArgs &a, hipStream_t st) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         n_cu[dev].store(cus, std::memory_order_relaxed);
     }
+    const size_t smem = ws_smem_bytes(C::NPIX, NSPLIT, 3, a.cin, PRO, C::MT, MF, C::NCW);
+    if (smem > (size_t)160 * 1024) return hipErrorInvalidValue;      // (conv_ws_eligible keeps such layers on conv_mfma.hip)
+    // persistent workgroups: one per CU for the eight-wave form; the two-wave form fits three per CU (LDS: three images each)
+    const int per_cu = C::NCW == 4 ? 1 : (int)std::min<size_t>(3, (size_t)160 * 1024 / smem);
     const long ntiles = (long)a.B * a.tiles_x * a.tiles_y * (a.cout / C::MT);
-    const int grid = (int)std::min<long>(ntiles, cus);
-    const size_t smem3 = ws_smem_bytes(C::NPIX, NSPLIT, 3, a.cin, PRO, C::MT, MF);
-    const bool ring3 = smem3 <= (size_t)160 * 1024;
-    auto go = [&](auto kern, size_t smem) -> hipError_t {
-        static std::atomic<size_t> attr_set[64];
-        if (smem > attr_set[dev].load(std::memory_order_relaxed)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            if (e != hipSuccess) return e;
-            attr_set[dev].store(smem, std::memory_order_relaxed);
-        }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, a);
-        return hipGetLastError();
-    };
-    if (ring3) return go(&conv3x3_ws_kernel<WM, WN, MF, NF, PRO, NSPLIT, AT, 3>, smem3);
-    const size_t smem2 = ws_smem_bytes(C::NPIX, NSPLIT, 2, a.cin, PRO, C::MT, MF);
-    if (smem2 > (size_t)160 * 1024) return hipErrorInvalidValue;
-    return go(&conv3x3_ws_kernel<WM, WN, MF, NF, PRO, NSPLIT, AT, 2>, smem2);
+    const int grid = (int)std::min<long>(ntiles, (long)cus * per_cu);
+    auto kern = &conv3x3_ws_kernel<WM, WN, MF, NF, PRO, NSPLIT, AT, 3>;
+    static std::atomic<size_t> attr_set[64];
+    if (smem > attr_set[dev].load(std::memory_order_relaxed)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_set[dev].store(smem, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), smem, st, a);
+    return hipGetLastError();
 }
 
 template <int PRO>
 static hipError_t launch_ws_pro(ConvArgs &a, hipStream_t st) {
 #ifdef GTTS_WS_PROBE      // compile-time probe builds (register / ISA inspection): one instantiation only
-    if constexpr (PRO == PRO_GN) return launch_ws_ring<2, 2, 2, 5, PRO_GN, 2, float>(a, st);
+    if constexpr (PRO == PRO_GN) return launch_ws_ring<2, 2, PRO_GN, 2, float>(a, st);
     else return hipErrorInvalidValue;
 #else
-    const bool wide = a.cout > 64;
-    if (a.act_bf16) {
-        if (a.nsplit > 1) return hipErrorInvalidValue;
-        return wide ? launch_ws_ring<2, 2, 2, 5, PRO, 1, __bf16>(a, st) : launch_ws_ring<1, 4, 2, 5, PRO, 1, __bf16>(a, st);
-    }
-    if (a.nsplit > 1) return wide ? launch_ws_ring<2, 2, 2, 5, PRO, 2, float>(a, st) : launch_ws_ring<1, 4, 2, 5, PRO, 2, float>(a, st);
-    return wide ? launch_ws_ring<2, 2, 2, 5, PRO, 1, float>(a, st) : launch_ws_ring<1, 4, 2, 5, PRO, 1, float>(a, st);
+    if (a.act_bf16 || a.nsplit != 2) return hipErrorInvalidValue;
+    if (conv_ws_small(a.cout, a.Hout, a.Wout, a.B)) return launch_ws_ring<1, 1, PRO, 2, float>(a, st);
+    return a.cout > 64 ? launch_ws_ring<2, 2, PRO, 2, float>(a, st) : launch_ws_ring<1, 4, PRO, 2, float>(a, st);
 #endif
 }
 
 hipError_t launch_conv_ws(const ConvArgs &a_in, hipStream_t st) {
     ConvArgs a = a_in;
-    if (!conv_ws_eligible(CONV_C3, a.c0, a.c1, a.cout, a.pro, a.epi)) return hipErrorInvalidValue;
+    if (!conv_ws_eligible(CONV_C3, a.c0, a.c1, a.cout, a.pro, a.epi, a.nsplit)) return hipErrorInvalidValue;
+    if (a.cin / 16 < 2) return hipErrorInvalidValue;
     return a.pro == PRO_GN ? launch_ws_pro<PRO_GN>(a, st) : launch_ws_pro<PRO_MASK>(a, st);
 }
 

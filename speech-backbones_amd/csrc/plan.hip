@@ -202,7 +202,7 @@ static void add_block(gtts_plan *p, const std::string &pre, const std::string &t
     int part = add_tensor(p, tname + ".part", TK_PART, p->cfg.groups, lvl);
     p->tensors[part].mode = CONV_C3;
     p->tensors[part].cout = cout;
-    p->tensors[part].ws = conv_ws_eligible(CONV_C3, c0, c1, cout, pro, EPI_STATS);
+    p->tensors[part].ws = conv_ws_eligible(CONV_C3, c0, c1, cout, pro, EPI_STATS, p->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1);
     *sc = add_tensor(p, tname + ".sc", TK_PERB, cout, 0);
     *sh = add_tensor(p, tname + ".sh", TK_PERB, cout, 0);
     Op c = blank_op(OP_CONV, tname + ".conv");
@@ -640,13 +640,18 @@ extern "C" int gtts_pack_weights(const gtts_plan *plan, const void *const *param
 }
 
 // ------------------------------------------------------------------------------------------------ workspace
+// GroupNorm partial slots per sample of a TK_PART tensor (the count its producing kernel writes)
+static int part_slots(const Tensor &t, int H, int W) {
+    return t.ws ? conv_ws_nparts(t.cout, H, W) : conv_nparts(t.mode, t.cout, H, W);
+}
+
 static size_t tensor_bytes(const gtts_plan *p, const Tensor &t, int B, int T, int rows, int Tr) {
     const int F = p->cfg.n_feats;
     const size_t H = (size_t)F >> t.lvl, W = (size_t)(t.tref ? Tr : T) >> t.lvl;
     switch (t.kind) {
         case TK_ACT: return (size_t)B * t.C * H * W * (p->cfg.precision == GTTS_PREC_BF16_STORE ? 2 : 4);
         case TK_PERB: return (size_t)B * t.C * 4;
-        case TK_PART: return (size_t)B * conv_nparts(t.mode, t.cout, (int)H, (int)W) * t.C * 2 * 4;
+        case TK_PART: return (size_t)B * part_slots(t, (int)H, (int)W) * t.C * 2 * 4;
         case TK_APART: return (size_t)B * 4 * attn_geom((int)(H * W), t.C).nrec * ATTN_REC * 4;
         case TK_BYTES_PERB: return (size_t)B * t.bytes;
         case TK_ROWS: return ((size_t)rows * p->tmlp.tb_stride + 4096) * 4;   // + the sampler's step times
@@ -749,11 +754,6 @@ extern "C" int gtts_vc_tensor_info(const gtts_plan *plan, int i, int B, int T, i
         if (t.kind == TK_ROWS) { dims[0] = B; dims[1] = p->tmlp.tb_stride; }   // first B rows (estimator call)
     }
     return GTTS_OK;
-}
-
-// GroupNorm partial slots per sample of a TK_PART tensor (the count its producing kernel writes)
-static int part_slots(const Tensor &t, int H, int W) {
-    return t.ws ? conv_ws_nparts(t.cout, H, W) : conv_nparts(t.mode, t.cout, H, W);
 }
 
 // ------------------------------------------------------------------------------------------------ execution
@@ -1370,11 +1370,14 @@ extern "C" int gtts_log_prior(const float *mu_x, const float *y, float *log_prio
 
 // ------------------------------------------------------------------------------------------------ measurement
 // the template instance launch_conv picks (conv_mfma.hip: launch_prec / launch_cfg), as rocprofv3 prints it
-static std::string conv_kernel_name(int mode, int cin, int cout, int pro, int epi, int nsplit, bool abf, bool small, bool ws) {
+static std::string conv_kernel_name(int mode, int cin, int cout, int pro, int epi, int nsplit, bool abf, bool small, bool ws, int B, int Ho,
+                                    int Wo) {
     const bool wide = cout > 64;
-    if (ws) {      // conv_ws.hip (ring of 3 images: every Grad-TTS / DiffVC layer fits)
+    if (ws) {      // conv_ws.hip
         char wb[128];
-        snprintf(wb, sizeof wb, "gtts::conv3x3_ws_kernel<%d, %d, 2, 5, %d, %d, %s, 3>", wide ? 2 : 1, wide ? 2 : 4, pro, nsplit, abf ? "__bf16" : "float");
+        const bool sm = conv_ws_small(cout, Ho, Wo, B);
+        snprintf(wb, sizeof wb, "gtts::conv3x3_ws_kernel<%d, %d, 2, 5, %d, %d, %s, 3>", sm ? 1 : (wide ? 2 : 1), sm ? 1 : (wide ? 2 : 4), pro, nsplit,
+                 abf ? "__bf16" : "float");
         return wb;
     }
     const int kch = conv_geom(mode, cin, cout).kch;
@@ -1429,7 +1432,7 @@ extern "C" int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, con
                 if (o.epi == EPI_TAIL || o.epi == EPI_ATTN) by += ab * B * o.cout * Ho * Wo;
                 s_kernel = conv_kernel_name(o.mode, o.c0 + o.c1, o.cout, o.pro, o.epi, plan->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1,
                                             plan->cfg.precision == GTTS_PREC_BF16_STORE, conv_small_tiles(o.mode, o.cout, Ho, Wo, B),
-                                            conv_ws_eligible(o.mode, o.c0, o.c1, o.cout, o.pro, o.epi));
+                                            conv_ws_eligible(o.mode, o.c0, o.c1, o.cout, o.pro, o.epi, plan->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1), B, (int)Ho, (int)Wo);
                 break;
             }
             case OP_GNFIN: s_kernel = "gtts::gn_finalize_kernel"; break;

@@ -31,11 +31,12 @@ class MaskedConv3x3(torch.autograd.Function):
         be = backend()
         x, cols, weight = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = None
+        dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = be.conv3x3_dgrad(dy, weight) * cols[:, None, None, :]
-        dw, db = be.conv3x3_wgrad(x, cols, dy)
-        return dx, None, dw, db
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:      # (one kernel produces both)
+            dw, db = be.conv3x3_wgrad(x, cols, dy)
+        return dx, None, (dw if ctx.needs_input_grad[2] else None), (db if ctx.needs_input_grad[3] else None)
 
 
 class GnMishMask(torch.autograd.Function):
@@ -90,7 +91,7 @@ def _conv_gn_mish(blk, v, m):
         y = MaskedConv3x3.apply(v.contiguous(), m, conv.weight, conv.bias)
     else:
         y = F.conv2d(v * m, conv.weight, conv.bias, padding=1)
-    if y.is_cuda and y.dtype == torch.float32 and not FORCE_TORCH:
+    if y.is_cuda and y.dtype == torch.float32 and not FORCE_TORCH and y.dim() == 4 and y.shape[1] % norm.num_groups == 0:
         return GnMishMask.apply(y.contiguous(), m, norm.weight, norm.bias, norm.num_groups, norm.eps)
     y = F.group_norm(y, norm.num_groups, norm.weight, norm.bias, norm.eps)
     return _mish(y) * m

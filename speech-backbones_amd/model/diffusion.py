@@ -272,7 +272,7 @@ class Diffusion(BaseModule):
     def forward_diffusion(self, x0, mask, mu, t):
         """diffusion.py:244-252.  HIP tensors: one fused kernel after the (reference-ordered) N(0,1) draw."""
         z = torch.randn(x0.shape, dtype=x0.dtype, device=x0.device, requires_grad=False)
-        if x0.is_cuda and not x0.requires_grad and not mu.requires_grad:
+        if x0.is_cuda and not x0.requires_grad and not mu.requires_grad and not _train_ops.FORCE_TORCH:
             return backend().diffusion_noising(x0, mu, z, mask, t, self.beta_min, self.beta_max)
         time = t[:, None, None]
         cum = get_noise(time, self.beta_min, self.beta_max, cumulative=True)
@@ -320,10 +320,11 @@ class Diffusion(BaseModule):
         """diffusion.py:281-288."""
         xt, z = self.forward_diffusion(x0, mask, mu, t)
         est = self.estimator(xt, mask, mu, t, spk)
-        if est.is_cuda:
-            # fused loss head: squared error reduction and d loss / d est in one pass (csrc/train.hip)
+        if est.is_cuda and not _train_ops.FORCE_TORCH:
+            # fused loss head: squared error reduction and d loss / d est in one pass (csrc/train.hip); the normaliser stays a
+            # device scalar (no host synchronisation per training step)
             inv_denom = 1.0 / (torch.sum(mask) * self.n_feats)
-            loss = _train_ops.ScoreLoss.apply(est.contiguous(), z, t, float(self.beta_min), float(self.beta_max), float(inv_denom))
+            loss = _train_ops.ScoreLoss.apply(est.contiguous(), z, t, float(self.beta_min), float(self.beta_max), inv_denom)
             return loss, xt
         cum = get_noise(t[:, None, None], self.beta_min, self.beta_max, cumulative=True)
         eps = est * torch.sqrt(1.0 - torch.exp(-cum))

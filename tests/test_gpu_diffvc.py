@@ -220,7 +220,7 @@ def test_diffvc_model_shell_drop_in(S, dev):
     from oracle import postnet_oracle as P
     M = importlib.import_module("speech-backbones_amd.diffvc.model")
     torch.manual_seed(1)
-    m = M.DiffVC(80, 64, 128, 2, 2, 3, 0.0, 4, 32, 128, True, 64, 0.05, 20.0).eval()
+    m = M.DiffVC(80, 64, 128, 2, 2, 3, 0.0, 4, 64, 128, True, 64, 0.05, 20.0).eval()
     with torch.no_grad():
         for n, prm in m.decoder.estimator.named_parameters():
             if n.endswith("fn.g"):

@@ -1,0 +1,14 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 900 python -m pytest "tests/test_gpu_diffvc.py::test_diffvc_model_shell_drop_in" "tests/test_gpu_training.py" "tests/test_gpu_parity_full.py::test_config3_bf16_store_n100_free_running_mel_scale" -m gpu -q -s -p no:cacheprovider > gpurun_out/r3a_tests.txt 2>&1; echo "pytest rc=$?"; grep -E "rel err|max\|err\||passed|failed|Error" gpurun_out/r3a_tests.txt | tail -12
+bash tools/gpu_fenced_check.sh 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r3a_fenced.txt
+timeout 600 python bench.py > gpurun_out/r3a_bench.json 2> gpurun_out/r3a_bench_tables.txt; echo "bench rc=$?"
+python - <<'PY'
+import json
+d = json.load(open('gpurun_out/r3a_bench.json'))
+print(d['value'], d['config']['ms_per_unet_call'], d['roofline']['kernel'], d['roofline']['avg_us'], d['roofline']['frac'], d['roofline'].get('frac_algorithmic'))
+for k, v in d.get('extras', {}).items():
+    print(k, {kk: vv for kk, vv in v.items() if kk not in ('workload', 'roofline')} if isinstance(v, dict) else v)
+    if isinstance(v, dict) and 'roofline' in v: print('   roofline:', v['roofline'].get('kernel'), v['roofline'].get('avg_us'), v['roofline'].get('frac'), v['roofline'].get('bound'))
+print(d.get('cpu_baseline'))
+PY
