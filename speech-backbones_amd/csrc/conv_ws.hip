@@ -18,11 +18,12 @@
 //              producer wave also combines the GroupNorm partial sums of a finished tile and runs the fused finalize.
 // One s_barrier per chunk hands an image over (ring of RING images, producers RING-1 chunks ahead).  The grid is
 // min(tiles, CUs) persistent workgroups walking tiles in XCD-banded order: the launch prologue is paid once per CU, and
-// the tile heights (10 rows for 128-channel tiles, 20 for 64) divide the 80 / 40 / 20 mel-bin levels, so B = 16 x 1024
-// frames is a whole number of rounds on 256 CUs on every level.
+// the 10-row tiles divide the 40 / 20 mel-bin levels, so B = 16 x 1024 frames is a whole number of rounds on 256 CUs.
+// Small launches (B = 1 ... 4: fewer regular tiles than CUs) take a three-wave workgroup -- one consumer wave on a
+// 32-channel x 5-row tile, two producer waves -- so that 4x as many CUs have work; see conv_ws_small().
 //
-// The tiling is a function of the layer geometry only (never of the batch size) and the GroupNorm partial sums are
-// formed in a fixed order, so results do not depend on how utterances are batched.
+// A GroupNorm partial slot is one consumer wave's sums over a (32-frame, 5-row) block in a fixed order in both forms, and the
+// accumulation order of an output never depends on the form, so results do not depend on how utterances are batched.
 #include "common.h"
 #include "kernels.h"
 #include <algorithm>
@@ -64,14 +65,16 @@ namespace gtts {
 
 template <int WM, int WN, int MF, int NF>
 struct WsCfg {
-    static constexpr int NCW = WM * WN;          // consumer waves (= producer waves): 4, or 1 in the small-launch form
-    static constexpr int NT = 2 * NCW * 64;      // threads per workgroup
+    static constexpr int NCW = WM * WN;          // consumer waves: 4, or 1 in the small-launch form
+    static constexpr int NPW = NCW == 1 ? 2 : NCW;   // producer waves (small form: a 32-channel consumer tile takes 4.3k cycles per
+                                                     // chunk, one producer wave needs 6k to stage it)
+    static constexpr int NT = (NCW + NPW) * 64;  // threads per workgroup
     static constexpr int MT = WM * MF * 32;      // output channels per workgroup
     static constexpr int TR = WN * NF;           // output rows per workgroup
     static constexpr int HR = TR + 2, HC = 34;   // halo tile
     static constexpr int NPIX = HR * HC;
     static constexpr int NKG = 2;                // 8-channel groups per 16-channel chunk
-    static_assert(NCW == 4 || NCW == 1, "four consumer waves, or one");
+    static_assert((NCW == 4 && MF == 2) || (NCW == 1 && MF == 1), "four consumer waves of 64 channels, or one of 32");
 };
 
 static inline size_t ws_smem_bytes(int npix, int nsplit, int ring, int cin, int pro, int mt, int mf, int ncw) {
@@ -81,10 +84,11 @@ static inline size_t ws_smem_bytes(int npix, int nsplit, int ring, int cin, int 
 }
 
 template <int WM, int WN, int MF, int NF, int PRO, int NSPLIT, typename AT, int RING>
-__global__ __launch_bounds__(WM * WN * 128, 2) void conv3x3_ws_kernel(const ConvArgs a) {
+__global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_kernel(const ConvArgs a) {
     using C = WsCfg<WM, WN, MF, NF>;
     constexpr int AB = (int)sizeof(AT);
-    constexpr int MT = C::MT, TR = C::TR, HC = C::HC, NPIX = C::NPIX, NKG = C::NKG, NCW = C::NCW, NPT = NCW * 64;
+    constexpr int MT = C::MT, TR = C::TR, HC = C::HC, NPIX = C::NPIX, NKG = C::NKG, NCW = C::NCW;
+    constexpr int NCT = NCW * 64, NPT = C::NPW * 64;   // consumer / producer threads
     constexpr int PLANE16 = NKG * NPIX;              // 16-byte units of one plane (hi or lo) of an image
     constexpr int IMG16 = NSPLIT * PLANE16;          // ... of one ring slot
     constexpr int D = RING - 1;                      // producers run D chunks ahead
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(WM * WN * 128, 2) void conv3x3_ws_kernel(const Conv
                     for (int ni = 0; ni < NF; ++ni)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-                for (int c = tid; c < MT; c += NPT) s_epi[par * MT + c] = a.bias[tl.cot * MT + c];
+                for (int c = tid; c < MT; c += NCT) s_epi[par * MT + c] = a.bias[tl.cot * MT + c];
             } else if (RING < 3) {
 #pragma unroll
                 for (int ni = 0; ni < NF; ++ni) xh[ni] = *reinterpret_cast<const bf16x8 *>(xh_p + ni * HC);
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(WM * WN * 128, 2) void conv3x3_ws_kernel(const Conv
         lds_barrier();                                              // (F) the last tile's wave sums are in s_red
     } else {
         // =================================================================================== PRODUCERS
-        const int ptid = tid - NPT;
+        const int ptid = tid - NCT;
         // A staging item is (8-channel group, halo row, GROUP OF FOUR consecutive frames): eight 16-byte loads (one per
         // channel; 8 bytes in bf16 storage) instead of thirty-two dword loads -- the texture path spends its address cycles
         // per instruction, and with dword loads the producers' requests alone kept it busy for a third of a chunk, in front of
@@ -686,40 +690,45 @@ __global__ __launch_bounds__(WM * WN * 128, 2) void conv3x3_ws_kernel(const Conv
 
 // ---------------------------------------------------------------------------------------------------- host side
 // Which Block convolutions take this kernel: 3x3, whole 16-channel chunks (a concatenated input splitting on a chunk
-// boundary), mask / GroupNorm prologue, statistics epilogue, at least 32 input channels, whole cout tiles -- and the
-// fp32-grade bf16x3 precision: the single-pass bf16 modes (BASELINE config 3) have a third of the MFMA work per staged value,
-// the four producer waves cannot keep up with the consumers there, and conv_mfma.hip's uniform waves on three sub-batch
-// streams are faster (measured: 5.9 vs 3.7 ms per U-Net call).
+// boundary), mask / GroupNorm prologue, statistics epilogue, at least 32 input channels, whole 128-channel cout tiles --
+// and the fp32-grade bf16x3 precision.  Left on conv_mfma.hip (measured, profiles/r03_conv_ws_findings.txt):
+//   * the single-pass bf16 modes (BASELINE config 3): a third of the MFMA work per staged value, the four producer waves
+//     cannot keep up with the consumers, and uniform waves on three sub-batch streams are faster (5.9 vs 3.7 ms per call);
+//   * 64 output channels: the same MFMA work needs twice the activation staging and has half the chunks per tile to spread
+//     the epilogue over; a 64 x 640 form of this kernel was level with conv_mfma.hip at 80 x 1024 (300 vs 306 us) and
+//     slower at 40 x 512 (92 vs 79 us).
 bool conv_ws_eligible(int mode, int c0, int c1, int cout, int pro, int epi, int nsplit) {
     const int cin = c0 + c1;
     if (!GTTS_WS || nsplit != 2) return false;
     if (mode != CONV_C3 || epi != EPI_STATS || (pro != PRO_MASK && pro != PRO_GN)) return false;
     if (cin % 16 != 0 || cin < 32 || (c1 != 0 && c0 % 16 != 0)) return false;
-    if (!(cout % 64 == 0 && (cout <= 64 || cout % 128 == 0))) return false;
+    if (cout % 128 != 0) return false;
     // three activation images + the per-channel parameters must fit the CU's LDS
-    const int npix = (cout <= 64 ? 22 : 12) * 34;
-    return ws_smem_bytes(npix, 2, 3, cin, pro, cout <= 64 ? 64 : 128, 2, 4) <= (size_t)160 * 1024;
+    return ws_smem_bytes(12 * 34, 2, 3, cin, pro, 128, 2, 4) <= (size_t)160 * 1024;
 }
 // GroupNorm partial slots per sample: one per (32-frame column block, 5-row band), whatever the workgroup shape
 int conv_ws_nparts(int cout, int Hout, int Wout) {
     (void)cout;
     return ((Wout + 31) / 32) * ((Hout + 4) / 5);
 }
-// A launch whose regular tiling (128 channels x 10 rows, or 64 x 20) gives fewer workgroups than this takes the small form:
-// one consumer + one producer wave per workgroup on a 64-channel x 5-row tile -- the SAME wave tile, so every output and
-// every partial sum is bit-identical and results do not depend on the batch size.
+// A launch whose regular tiling (128 channels x 10 rows) gives fewer workgroups than this takes the small form: one consumer
+// wave on a 32-channel x 5-row tile + two producer waves per workgroup.  A wave's accumulators see the same chunk / pass /
+// tap order, a partial slot is still ONE wave's sums over the same five rows, and a group's channel octets are added in
+// the same order, so every output and every partial sum is bit-identical to the regular form: results do not depend on
+// the batch size.  (Groups wider than the 32-channel tile -- DiffVC's 512- and 1024-channel levels -- stay on the regular
+// form: two tiles would share a slot.)
 #ifndef GTTS_WS_SMALL_WGS
 #define GTTS_WS_SMALL_WGS 160
 #endif
-bool conv_ws_small(int cout, int Hout, int Wout, int B) {
-    const int mt = cout <= 64 ? 64 : 128, tr = cout <= 64 ? 20 : 10;
-    const long wgs = (long)B * ((Wout + 31) / 32) * ((Hout + tr - 1) / tr) * (cout / mt);
+bool conv_ws_small(int cout, int groups, int Hout, int Wout, int B) {
+    if (groups <= 0 || cout / groups > 32) return false;
+    const long wgs = (long)B * ((Wout + 31) / 32) * ((Hout + 9) / 10) * (cout / 128);
     return wgs < GTTS_WS_SMALL_WGS;
 }
 
-template <int WM, int WN, int PRO, int NSPLIT, typename AT>
+template <int WM, int WN, int MF, int PRO, int NSPLIT, typename AT>
 static hipError_t launch_ws_ring(ConvArgs &a, hipStream_t st) {
-    constexpr int MF = 2, NF = 5;
+    constexpr int NF = 5;
     using C = WsCfg<WM, WN, MF, NF>;
     a.nchunk = a.cin / 16;
     a.tiles_x = (a.Wout + 31) / 32;
@@ -740,8 +749,8 @@ static hipError_t launch_ws_ring(ConvArgs &a, hipStream_t st) {
     }
     const size_t smem = ws_smem_bytes(C::NPIX, NSPLIT, 3, a.cin, PRO, C::MT, MF, C::NCW);
     if (smem > (size_t)160 * 1024) return hipErrorInvalidValue;      // (conv_ws_eligible keeps such layers on conv_mfma.hip)
-    // persistent workgroups: one per CU for the eight-wave form; the two-wave form fits three per CU (LDS: three images each)
-    const int per_cu = C::NCW == 4 ? 1 : (int)std::min<size_t>(3, (size_t)160 * 1024 / smem);
+    // persistent workgroups: one per CU for the eight-wave form; the three-wave form fits two per CU (registers: 8 waves)
+    const int per_cu = C::NCW == 4 ? 1 : (int)std::min<size_t>(2, (size_t)160 * 1024 / smem);
     const long ntiles = (long)a.B * a.tiles_x * a.tiles_y * (a.cout / C::MT);
     const int grid = (int)std::min<long>(ntiles, (long)cus * per_cu);
     auto kern = &conv3x3_ws_kernel<WM, WN, MF, NF, PRO, NSPLIT, AT, 3>;
@@ -758,12 +767,12 @@ static hipError_t launch_ws_ring(ConvArgs &a, hipStream_t st) {
 template <int PRO>
 static hipError_t launch_ws_pro(ConvArgs &a, hipStream_t st) {
 #ifdef GTTS_WS_PROBE      // compile-time probe builds (register / ISA inspection): one instantiation only
-    if constexpr (PRO == PRO_GN) return launch_ws_ring<2, 2, PRO_GN, 2, float>(a, st);
+    if constexpr (PRO == PRO_GN) return launch_ws_ring<GTTS_WS_PROBE == 1 ? 1 : 2, GTTS_WS_PROBE == 1 ? 1 : 2, GTTS_WS_PROBE == 1 ? 1 : 2, PRO_GN, 2, float>(a, st);
     else return hipErrorInvalidValue;
 #else
     if (a.act_bf16 || a.nsplit != 2) return hipErrorInvalidValue;
-    if (conv_ws_small(a.cout, a.Hout, a.Wout, a.B)) return launch_ws_ring<1, 1, PRO, 2, float>(a, st);
-    return a.cout > 64 ? launch_ws_ring<2, 2, PRO, 2, float>(a, st) : launch_ws_ring<1, 4, PRO, 2, float>(a, st);
+    if (conv_ws_small(a.cout, a.groups, a.Hout, a.Wout, a.B)) return launch_ws_ring<1, 1, 1, PRO, 2, float>(a, st);
+    return launch_ws_ring<2, 2, 2, PRO, 2, float>(a, st);
 #endif
 }
 

@@ -1371,12 +1371,12 @@ extern "C" int gtts_log_prior(const float *mu_x, const float *y, float *log_prio
 // ------------------------------------------------------------------------------------------------ measurement
 // the template instance launch_conv picks (conv_mfma.hip: launch_prec / launch_cfg), as rocprofv3 prints it
 static std::string conv_kernel_name(int mode, int cin, int cout, int pro, int epi, int nsplit, bool abf, bool small, bool ws, int B, int Ho,
-                                    int Wo) {
+                                    int Wo, int groups) {
     const bool wide = cout > 64;
-    if (ws) {      // conv_ws.hip
+    if (ws) {      // conv_ws.hip (launch_ws_pro)
         char wb[128];
-        const bool sm = conv_ws_small(cout, Ho, Wo, B);
-        snprintf(wb, sizeof wb, "gtts::conv3x3_ws_kernel<%d, %d, 2, 5, %d, %d, %s, 3>", sm ? 1 : (wide ? 2 : 1), sm ? 1 : (wide ? 2 : 4), pro, nsplit,
+        const bool sm = conv_ws_small(cout, groups, Ho, Wo, B);
+        snprintf(wb, sizeof wb, "gtts::conv3x3_ws_kernel<%d, %d, %d, 5, %d, %d, %s, 3>", sm ? 1 : 2, sm ? 1 : 2, sm ? 1 : 2, pro, nsplit,
                  abf ? "__bf16" : "float");
         return wb;
     }
@@ -1432,7 +1432,7 @@ extern "C" int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, con
                 if (o.epi == EPI_TAIL || o.epi == EPI_ATTN) by += ab * B * o.cout * Ho * Wo;
                 s_kernel = conv_kernel_name(o.mode, o.c0 + o.c1, o.cout, o.pro, o.epi, plan->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1,
                                             plan->cfg.precision == GTTS_PREC_BF16_STORE, conv_small_tiles(o.mode, o.cout, Ho, Wo, B),
-                                            conv_ws_eligible(o.mode, o.c0, o.c1, o.cout, o.pro, o.epi, plan->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1), B, (int)Ho, (int)Wo);
+                                            conv_ws_eligible(o.mode, o.c0, o.c1, o.cout, o.pro, o.epi, plan->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1), B, (int)Ho, (int)Wo, plan->cfg.groups);
                 break;
             }
             case OP_GNFIN: s_kernel = "gtts::gn_finalize_kernel"; break;
