@@ -4,6 +4,7 @@ PyTorch is only plumbing here: it owns device memory (packed weights, workspace,
 There is NO fallback: if the library is missing or a call fails, a RuntimeError is raised.
 """
 import ctypes
+import weakref
 import os
 import threading
 
@@ -92,6 +93,34 @@ def lib():
         L.gtts_conv3x3_wgrad_workspace_bytes.argtypes = [i, i, i, i, i]
         L.gtts_conv3x3_wgrad_workspace_bytes.restype = sz
         L.gtts_conv3x3_wgrad_tiled.argtypes = [vp, vp, vp, vp, vp, vp, sz, i, i, i, i, i, vp]
+        L.gtts_conv1x1_packed_bytes.argtypes = [i, i]
+        L.gtts_conv1x1_packed_bytes.restype = sz
+        L.gtts_conv1x1_pack.argtypes = [vp, vp, i, i, i, vp]
+        L.gtts_conv1x1_masked.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, vp]
+        L.gtts_conv1x1_wgrad_workspace_bytes.argtypes = [i, i, i, i, i]
+        L.gtts_conv1x1_wgrad_workspace_bytes.restype = sz
+        L.gtts_conv1x1_wgrad.argtypes = [vp, vp, vp, vp, vp, vp, sz, i, i, i, i, i, vp]
+        L.gtts_conv3x3_masked2.argtypes = [vp, vp, i, vp, vp, vp, vp, i, i, i, i, i, vp]
+        L.gtts_conv3x3_wgrad_tiled2.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, sz, i, i, i, i, i, vp]
+        L.gtts_conv_resample_packed_bytes.argtypes = [i, i, i]
+        L.gtts_conv_resample_packed_bytes.restype = sz
+        L.gtts_conv_resample_pack.argtypes = [vp, vp, i, i, i, vp]
+        L.gtts_conv_resample.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
+        L.gtts_gn_mish_forward_tb.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, f, vp]
+        L.gtts_gn_mish_backward_tb.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, vp]
+        L.gtts_add_masked.argtypes = [vp, vp, vp, vp, i, i, i, i, i, vp]
+        L.gtts_final_conv_forward.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp]
+        L.gtts_final_conv_scratch_floats.argtypes = [i, i, i, i]
+        L.gtts_final_conv_scratch_floats.restype = sz
+        L.gtts_final_conv_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, vp]
+        L.gtts_attn_train_scratch_floats.argtypes = [i, i]
+        L.gtts_attn_train_scratch_floats.restype = sz
+        L.gtts_attn_train_forward.argtypes = [vp, vp, vp, vp, vp, i, i, vp]
+        L.gtts_attn_train_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp]
+        L.gtts_rezero_forward.argtypes = [vp, vp, vp, vp, sz, vp]
+        L.gtts_rezero_scratch_bytes.argtypes = [sz]
+        L.gtts_rezero_scratch_bytes.restype = sz
+        L.gtts_rezero_backward.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp]
         L.gtts_gn_mish_forward.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, f, vp]
         L.gtts_gn_mish_stats_floats.argtypes = [i, i]
         L.gtts_gn_mish_stats_floats.restype = sz
@@ -806,22 +835,41 @@ def conv3x3_supported(cin, cout):
     return cin % 32 == 0 and cout % 32 == 0 and tiles(cin) and tiles(cout)
 
 
-_PACKED = {}       # (device, weight storage, weight version, transposed) -> packed blob; an optimizer step bumps the version
+_PACKED = {}       # (id(weight), transposed, kind) -> (weakref to the weight, its version, packed blob)
 _CONSTS = {}       # (device, kind, n) -> ones / zeros of the data-gradient call
 
 
-def _packed_conv3x3(weight, cin, cout, transposed):
-    key = (str(weight.device), weight.data_ptr(), int(weight._version), bool(transposed), cin, cout)
+def _packed_weight(weight, cin, cout, transposed, kind):
+    """Packed (fragment-order, bf16 hi / lo) copy of a convolution weight, cached per Parameter OBJECT and version: the entry is
+    valid only while the very same tensor object is alive and unmodified (an optimizer step bumps `_version`; a data pointer
+    alone can be recycled by the caching allocator for a different weight of the same shape)."""
+    key = (id(weight), bool(transposed), kind)
     hit = _PACKED.get(key)
-    if hit is not None:
-        return hit
+    if hit is not None and hit[0]() is weight and hit[1] == int(weight._version) and hit[2].device == weight.device:
+        return hit[2]
     L = lib()
-    packed = torch.empty(int(L.gtts_conv3x3_packed_bytes(cin, cout)), dtype=torch.uint8, device=weight.device)
-    _check(L.gtts_conv3x3_pack(_ptr(weight), _ptr(packed), cin, cout, 1 if transposed else 0, _stream()), "gtts_conv3x3_pack")
-    if len(_PACKED) >= 256:          # (two entries per Block convolution: 50 for the Grad-TTS U-Net)
-        _PACKED.clear()
-    _PACKED[key] = packed
+    if kind in ("3x3", "1x1"):
+        nbytes, pack = ((L.gtts_conv3x3_packed_bytes, L.gtts_conv3x3_pack) if kind == "3x3" else (L.gtts_conv1x1_packed_bytes, L.gtts_conv1x1_pack))
+        packed = torch.empty(int(nbytes(cin, cout)), dtype=torch.uint8, device=weight.device)
+        _check(pack(_ptr(weight), _ptr(packed), cin, cout, 1 if transposed else 0, _stream()), "gtts_conv%s_pack" % kind)
+    else:
+        # "dn" Downsample forward, "up" Upsample forward, "dn_T" Downsample's data gradient: an Upsample of dy with the forward
+        # weight [cout][cin][3][3] zero-padded to [.][.][4][4] (ConvTranspose2d layout: [in = cout][out = cin])
+        up = 0 if kind == "dn" else 1
+        src = torch.nn.functional.pad(weight, (0, 1, 0, 1)).contiguous() if kind == "dn_T" else weight
+        packed = torch.empty(int(L.gtts_conv_resample_packed_bytes(cin, cout, up)), dtype=torch.uint8, device=weight.device)
+        _check(L.gtts_conv_resample_pack(_ptr(src), _ptr(packed), cin, cout, up, _stream()), "gtts_conv_resample_pack")
+    if len(_PACKED) >= 512:          # (two entries per convolution: ~100 for the Grad-TTS U-Net); dead entries go with the sweep
+        for k in [k for k, v in _PACKED.items() if v[0]() is None]:
+            del _PACKED[k]
+        if len(_PACKED) >= 512:
+            _PACKED.clear()
+    _PACKED[key] = (weakref.ref(weight), int(weight._version), packed)
     return packed
+
+
+def _packed_conv3x3(weight, cin, cout, transposed):
+    return _packed_weight(weight, cin, cout, transposed, "3x3")
 
 
 def _const(device, kind, *shape):
@@ -833,22 +881,24 @@ def _const(device, kind, *shape):
     return v
 
 
-def _conv3x3_run(x, mask_cols, weight, bias, transposed):
-    B, cin, H, W = x.shape
+def _conv3x3_run(x, mask_cols, weight, bias, transposed, x1=None):
+    B, c0, H, W = x.shape
+    cin = c0 + (int(x1.shape[1]) if x1 is not None else 0)
     cout = weight.shape[1] if transposed else weight.shape[0]
     L = lib()
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         packed = _packed_conv3x3(weight, cin, cout, transposed)
-        _check(L.gtts_conv3x3_masked(_ptr(x), _ptr(mask_cols), _ptr(packed), _ptr(bias), _ptr(y), B, cin, cout, H, W, _stream()),
-               "gtts_conv3x3_masked")
+        _check(L.gtts_conv3x3_masked2(_ptr(x), _ptr(x1), c0, _ptr(mask_cols), _ptr(packed), _ptr(bias), _ptr(y), B, cin, cout, H, W,
+                                      _stream()), "gtts_conv3x3_masked")
     return y
 
 
-def conv3x3_masked(x, mask_cols, weight, bias):
-    """Conv2d_3x3(x * mask) + bias (Block.forward, diffusion.py:56-57): x [B,cin,H,W], mask_cols [B,W], weight [cout,cin,3,3]."""
+def conv3x3_masked(x, mask_cols, weight, bias, x1=None):
+    """Conv2d_3x3(cat(x, x1) * mask) + bias (Block.forward, diffusion.py:56-57; the concatenation of the up path, :166, is read in
+    place): x [B,c0,H,W], x1 [B,c1,H,W] or None, mask_cols [B,W], weight [cout,c0+c1,3,3]."""
     x, mask_cols, weight, bias = _f32c(x, "x"), _f32c(mask_cols, "mask"), _f32c(weight, "weight"), _f32c(bias, "bias")
-    return _conv3x3_run(x, mask_cols, weight, bias, False)
+    return _conv3x3_run(x, mask_cols, weight, bias, False, _f32c(x1, "x1"))
 
 
 def conv3x3_dgrad(dy, weight):
@@ -858,10 +908,11 @@ def conv3x3_dgrad(dy, weight):
     return _conv3x3_run(dy, _const(dy.device, "ones", B, W), weight, _const(dy.device, "zeros", int(weight.shape[1])), True)
 
 
-def conv3x3_wgrad(x, mask_cols, dy):
-    """(dW [cout,cin,3,3], db [cout]) of conv3x3_masked."""
-    x, mask_cols, dy = _f32c(x, "x"), _f32c(mask_cols, "mask"), _f32c(dy, "dy")
-    B, cin, H, W = x.shape
+def conv3x3_wgrad(x, mask_cols, dy, x1=None):
+    """(dW [cout,cin,3,3], db [cout]) of conv3x3_masked (x1: second source of a concatenated input, c0 a multiple of 64)."""
+    x, mask_cols, dy, x1 = _f32c(x, "x"), _f32c(mask_cols, "mask"), _f32c(dy, "dy"), _f32c(x1, "x1")
+    B, c0, H, W = x.shape
+    cin = c0 + (int(x1.shape[1]) if x1 is not None else 0)
     cout = dy.shape[1]
     dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
     db = torch.empty((cout,), dtype=torch.float32, device=x.device)
@@ -869,39 +920,217 @@ def conv3x3_wgrad(x, mask_cols, dy):
         if cin % 64 == 0 and cout % 64 == 0:       # LDS-tiled deterministic reduction (train_wgrad.hip)
             nws = int(lib().gtts_conv3x3_wgrad_workspace_bytes(B, cin, cout, H, W))
             ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
-            _check(lib().gtts_conv3x3_wgrad_tiled(_ptr(x), _ptr(mask_cols), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), nws, B, cin, cout,
-                                                  H, W, _stream()), "gtts_conv3x3_wgrad_tiled")
+            _check(lib().gtts_conv3x3_wgrad_tiled2(_ptr(x), _ptr(x1), c0, _ptr(mask_cols), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), nws,
+                                                   B, cin, cout, H, W, _stream()), "gtts_conv3x3_wgrad_tiled")
         else:
+            if x1 is not None:
+                x = torch.cat((x, x1), 1)
             _check(lib().gtts_conv3x3_wgrad(_ptr(x), _ptr(mask_cols), _ptr(dy), _ptr(dw), _ptr(db), B, cin, cout, H, W, _stream()),
                    "gtts_conv3x3_wgrad")
     return dw, db
 
 
-def gn_mish_forward(y, gamma, beta, mask_cols, groups, eps):
-    """(Mish(GroupNorm(y)) * mask, stats: (mean, rstd) pairs followed by reduction scratch) -- Block.forward after the convolution (diffusion.py:53-58)."""
-    y, gamma, beta, mask_cols = _f32c(y, "y"), _f32c(gamma, "gamma"), _f32c(beta, "beta"), _f32c(mask_cols, "mask")
+def conv1x1_supported(cin, cout, need_dgrad=True):
+    """Channel counts the 1x1 training kernels take: forward cout (and, for the data gradient, cin) a whole number of the
+    kernel's output tiles; the weight gradient whole 64 x 64 tiles."""
+    def tiles(c):
+        return c == 64 or (c > 64 and c % 128 == 0)
+    return tiles(cout) and cin % 64 == 0 and (tiles(cin) or not need_dgrad)
+
+
+def _packed_conv1x1(weight, cin, cout, transposed):
+    return _packed_weight(weight, cin, cout, transposed, "1x1")
+
+
+def _conv1x1_run(x, mask_cols, weight, bias, transposed):
+    B, cin, H, W = x.shape
+    cout = weight.shape[1] if transposed else weight.shape[0]
+    y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        packed = _packed_conv1x1(weight, cin, cout, transposed)
+        _check(lib().gtts_conv1x1_masked(_ptr(x), _ptr(mask_cols), _ptr(packed), _ptr(bias), _ptr(y), B, cin, cout, H, W, _stream()),
+               "gtts_conv1x1_masked")
+    return y
+
+
+def conv1x1_masked(x, mask_cols, weight, bias):
+    """Conv2d_1x1(x * mask) + bias (res_conv / to_qkv / to_out, diffusion.py:70,87-88): x [B,cin,H,W], mask_cols [B,W] or None,
+    weight [cout,cin,1,1], bias [cout] or None."""
+    x, weight = _f32c(x, "x"), _f32c(weight, "weight")
+    B, W = int(x.shape[0]), int(x.shape[3])
+    mask_cols = _const(x.device, "ones", B, W) if mask_cols is None else _f32c(mask_cols, "mask")
+    bias = _const(x.device, "zeros", int(weight.shape[0])) if bias is None else _f32c(bias, "bias")
+    return _conv1x1_run(x, mask_cols, weight, bias, False)
+
+
+def conv1x1_dgrad(dy, weight, mask_cols=None):
+    """Gradient of conv1x1_masked w.r.t. x: the 1x1 convolution of dy * mask (columns do not mix) with the transposed weight."""
+    dy, weight = _f32c(dy, "dy"), _f32c(weight, "weight")
+    B, W = int(dy.shape[0]), int(dy.shape[3])
+    mask_cols = _const(dy.device, "ones", B, W) if mask_cols is None else _f32c(mask_cols, "mask")
+    return _conv1x1_run(dy, mask_cols, weight, _const(dy.device, "zeros", int(weight.shape[1])), True)
+
+
+def conv1x1_wgrad(x, mask_cols, dy, want_bias=True):
+    """(dW [cout,cin,1,1], db [cout] or None) of conv1x1_masked."""
+    x, dy = _f32c(x, "x"), _f32c(dy, "dy")
+    B, cin, H, W = x.shape
+    cout = int(dy.shape[1])
+    dw = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=x.device)
+    db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    with torch.cuda.device(x.device):
+        nws = int(lib().gtts_conv1x1_wgrad_workspace_bytes(B, cin, cout, H, W))
+        ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
+        _check(lib().gtts_conv1x1_wgrad(_ptr(x), _ptr(_f32c(mask_cols, "mask")) if mask_cols is not None else None, _ptr(dy), _ptr(dw),
+                                        _ptr(db) if db is not None else None, _ptr(ws), nws, B, cin, cout, H, W, _stream()),
+               "gtts_conv1x1_wgrad")
+    return dw, db
+
+
+def add_masked(a, b, mask_cols, channels=None):
+    """a + b * mask (a None: b * mask; mask_cols None: a + b) over [B,C,H,W] with mask_cols [B,W].  channels = (c_begin, c_end):
+    b is that channel range of a wider contiguous tensor (read in place; the result is contiguous)."""
+    a, b, mask_cols = _f32c(a, "a"), _f32c(b, "b"), _f32c(mask_cols, "mask")
+    B, Cb, H, W = b.shape
+    c0, c1 = (0, Cb) if channels is None else channels
+    out = torch.empty((B, c1 - c0, H, W), dtype=torch.float32, device=b.device)
+    with torch.cuda.device(b.device):
+        _check(lib().gtts_add_masked(_ptr(a), ctypes.c_void_p(b.data_ptr() + 4 * c0 * H * W), _ptr(mask_cols), _ptr(out), B, c1 - c0, H, W,
+                                     0 if channels is None else Cb, _stream()), "gtts_add_masked")
+    return out
+
+
+def final_conv_forward(x, weight, bias, mask_cols):
+    """(Conv2d_1x1(x * mask) + bias) * mask for the 64 -> 1 final convolution (diffusion.py:175-176): [B,1,H,W]."""
+    x, weight, bias, mask_cols = _f32c(x, "x"), _f32c(weight, "weight"), _f32c(bias, "bias"), _f32c(mask_cols, "mask")
+    B, C, H, W = x.shape
+    out = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().gtts_final_conv_forward(_ptr(x), _ptr(weight), _ptr(bias), _ptr(mask_cols), _ptr(out), B, C, H, W, _stream()),
+               "gtts_final_conv_forward")
+    return out
+
+
+def final_conv_backward(x, weight, mask_cols, dout):
+    """(dx, dweight [1,C,1,1], dbias [1]) of final_conv_forward."""
+    x, weight, mask_cols, dout = _f32c(x, "x"), _f32c(weight, "weight"), _f32c(mask_cols, "mask"), _f32c(dout, "dout")
+    B, C, H, W = x.shape
+    dx = torch.empty_like(x)
+    dw = torch.empty((1, C, 1, 1), dtype=torch.float32, device=x.device)
+    db = torch.empty((1,), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        scratch = torch.empty(int(lib().gtts_final_conv_scratch_floats(B, C, H, W)), dtype=torch.float32, device=x.device)
+        _check(lib().gtts_final_conv_backward(_ptr(x), _ptr(weight), _ptr(mask_cols), _ptr(dout), _ptr(dx), _ptr(dw), _ptr(db),
+                                              _ptr(scratch), B, C, H, W, _stream()), "gtts_final_conv_backward")
+    return dx, dw, db
+
+
+def resample_supported(cin, cout, H, W, up):
+    def tiles(c):
+        return c == 64 or (c > 64 and c % 128 == 0)
+    return tiles(cin) and tiles(cout) and (up or (H % 2 == 0 and W % 2 == 0))
+
+
+def conv_resample(x, mask_cols, weight, bias, up, dgrad_of_down=False):
+    """Downsample (up False: Conv2d 3x3 stride 2 pad 1, weight [cout,cin,3,3]) or Upsample (up True: ConvTranspose2d 4x4 stride 2
+    pad 1, weight [cin,cout,4,4]) of x * mask (diffusion.py:19-34).  dgrad_of_down: x is the gradient of a Downsample output and
+    weight that Downsample's forward weight; the result is its data gradient (an Upsample with the zero-padded kernel)."""
+    x, mask_cols, weight = _f32c(x, "x"), _f32c(mask_cols, "mask"), _f32c(weight, "weight")
+    B, cin, H, W = x.shape
+    if dgrad_of_down:
+        cout, kind, up = int(weight.shape[1]), "dn_T", True
+    else:
+        cout, kind = (int(weight.shape[1]), "up") if up else (int(weight.shape[0]), "dn")
+    bias = _const(x.device, "zeros", cout) if bias is None else _f32c(bias, "bias")
+    y = torch.empty((B, cout, 2 * H, 2 * W) if up else (B, cout, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        packed = _packed_weight(weight, cin, cout, False, kind)
+        _check(lib().gtts_conv_resample(_ptr(x), _ptr(mask_cols), _ptr(packed), _ptr(bias), _ptr(y), B, cin, cout, H, W, 1 if up else 0,
+                                        _stream()), "gtts_conv_resample")
+    return y
+
+
+def attn_train_forward(qkv):
+    """LinearAttention core (diffusion.py:90-100) on to_qkv's output qkv [B,384,H,W]: (out [B,128,H,W], ctx [B,4,32,32],
+    stat [B,4,32,2] = softmax row maxima and reciprocal sums)."""
+    qkv = _f32c(qkv, "qkv")
+    B, C3, H, W = qkv.shape
+    if C3 != 384:
+        raise ValueError("attn_train_forward: to_qkv output must have 3 x 4 heads x 32 = 384 channels, got %d" % C3)
+    N = H * W
+    out = torch.empty((B, 128, H, W), dtype=torch.float32, device=qkv.device)
+    ctx = torch.empty((B, 4, 32, 32), dtype=torch.float32, device=qkv.device)
+    stat = torch.empty((B, 4, 32, 2), dtype=torch.float32, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        scratch = torch.empty(int(lib().gtts_attn_train_scratch_floats(B, N)), dtype=torch.float32, device=qkv.device)
+        _check(lib().gtts_attn_train_forward(_ptr(qkv), _ptr(out), _ptr(ctx), _ptr(stat), _ptr(scratch), B, N, _stream()),
+               "gtts_attn_train_forward")
+    return out, ctx, stat
+
+
+def attn_train_backward(qkv, dout, ctx, stat):
+    """d qkv of attn_train_forward given d out."""
+    qkv, dout = _f32c(qkv, "qkv"), _f32c(dout, "dout")
+    B, C3, H, W = qkv.shape
+    N = H * W
+    dqkv = torch.empty_like(qkv)
+    dctx = torch.empty((B, 4, 32, 32), dtype=torch.float32, device=qkv.device)
+    rdot = torch.empty((B, 4, 32), dtype=torch.float32, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        scratch = torch.empty(int(lib().gtts_attn_train_scratch_floats(B, N)), dtype=torch.float32, device=qkv.device)
+        _check(lib().gtts_attn_train_backward(_ptr(qkv), _ptr(dout), _ptr(ctx), _ptr(stat), _ptr(dqkv), _ptr(dctx), _ptr(rdot),
+                                              _ptr(scratch), B, N, _stream()), "gtts_attn_train_backward")
+    return dqkv
+
+
+def rezero_forward(f, g, x):
+    """f * g + x (Rezero + Residual, diffusion.py:40-46,103-108); g a 1-element device tensor."""
+    f, x, g = _f32c(f, "f"), _f32c(x, "x"), _f32c(g, "g")
+    y = torch.empty_like(f)
+    with torch.cuda.device(f.device):
+        _check(lib().gtts_rezero_forward(_ptr(f), _ptr(x), _ptr(g), _ptr(y), f.numel(), _stream()), "gtts_rezero_forward")
+    return y
+
+
+def rezero_backward(dy, f, g):
+    """(d f = dy * g, d g = sum(dy * f)) of rezero_forward."""
+    dy, f, g = _f32c(dy, "dy"), _f32c(f, "f"), _f32c(g, "g")
+    df = torch.empty_like(f)
+    dg = torch.empty_like(g)
+    with torch.cuda.device(f.device):
+        scratch = torch.empty(int(lib().gtts_rezero_scratch_bytes(f.numel())), dtype=torch.uint8, device=f.device)
+        _check(lib().gtts_rezero_backward(_ptr(dy), _ptr(f), _ptr(g), _ptr(df), _ptr(dg), _ptr(scratch), f.numel(), _stream()),
+               "gtts_rezero_backward")
+    return df, dg
+
+
+def gn_mish_forward(y, gamma, beta, mask_cols, groups, eps, tb=None):
+    """(Mish(GroupNorm(y)) * mask [+ tb[:, :, None, None]], stats: (mean, rstd) pairs followed by reduction scratch) -- Block.forward
+    after the convolution (diffusion.py:53-58) and, with tb [B,C], ResnetBlock's time term (diffusion.py:75-76)."""
+    y, gamma, beta, mask_cols, tb = _f32c(y, "y"), _f32c(gamma, "gamma"), _f32c(beta, "beta"), _f32c(mask_cols, "mask"), _f32c(tb, "tb")
     B, C, H, W = y.shape
     out = torch.empty_like(y)
     stats = torch.empty(int(lib().gtts_gn_mish_stats_floats(B, int(groups))), dtype=torch.float32, device=y.device)
     with torch.cuda.device(y.device):
-        _check(lib().gtts_gn_mish_forward(_ptr(y), _ptr(gamma), _ptr(beta), _ptr(mask_cols), _ptr(out), _ptr(stats), B, C, H, W,
-                                          int(groups), float(eps), _stream()), "gtts_gn_mish_forward")
+        _check(lib().gtts_gn_mish_forward_tb(_ptr(y), _ptr(gamma), _ptr(beta), _ptr(mask_cols), _ptr(tb), _ptr(out), _ptr(stats), B, C,
+                                             H, W, int(groups), float(eps), _stream()), "gtts_gn_mish_forward")
     return out, stats
 
 
-def gn_mish_backward(dout, y, gamma, beta, mask_cols, stats, groups):
-    """(dy, dgamma, dbeta) of gn_mish_forward."""
+def gn_mish_backward(dout, y, gamma, beta, mask_cols, stats, groups, want_dtb=False):
+    """(dy, dgamma, dbeta[, dtb [B,C]]) of gn_mish_forward."""
     dout, y = _f32c(dout, "dout"), _f32c(y, "y")
     B, C, H, W = y.shape
     dy = torch.empty_like(y)
     dg = torch.empty((C,), dtype=torch.float32, device=y.device)
     db = torch.empty((C,), dtype=torch.float32, device=y.device)
+    dtb = torch.empty((B, C), dtype=torch.float32, device=y.device) if want_dtb else None
     scratch = torch.empty(int(lib().gtts_gn_mish_scratch_bytes(B, C)), dtype=torch.uint8, device=y.device)
     with torch.cuda.device(y.device):
-        _check(lib().gtts_gn_mish_backward(_ptr(dout), _ptr(y), _ptr(_f32c(gamma, "gamma")), _ptr(_f32c(beta, "beta")),
-                                           _ptr(_f32c(mask_cols, "mask")), _ptr(stats), _ptr(dy), _ptr(dg), _ptr(db), _ptr(scratch),
-                                           B, C, H, W, int(groups), _stream()), "gtts_gn_mish_backward")
-    return dy, dg, db
+        _check(lib().gtts_gn_mish_backward_tb(_ptr(dout), _ptr(y), _ptr(_f32c(gamma, "gamma")), _ptr(_f32c(beta, "beta")),
+                                              _ptr(_f32c(mask_cols, "mask")), _ptr(stats), _ptr(dy), _ptr(dg), _ptr(db), _ptr(dtb),
+                                              _ptr(scratch), B, C, H, W, int(groups), _stream()), "gtts_gn_mish_backward")
+    return (dy, dg, db, dtb) if want_dtb else (dy, dg, db)
 
 
 def diffusion_noising(x0, mu, z, mask, t, beta_min, beta_max):

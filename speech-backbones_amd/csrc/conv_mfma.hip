@@ -940,7 +940,7 @@ int conv_nparts(int mode, int cout, int Hout, int Wout) {
 
 // (mode, tiling) x (prologue, epilogue) x precision -> template instance; must agree with conv_geom() in common.h.
 // Only the combinations the op program uses are instantiated:
-//   C3: (MASK | GN, STATS)   DN, UP: (MASK, PLAIN)   P1: (MASK, TAIL) | (PLAIN, ATTN)
+//   C3: (MASK | GN, STATS)   DN, UP: (MASK, PLAIN)   P1: (MASK, TAIL) | (PLAIN, ATTN) | (MASK, PLAIN: training)
 template <int MODE, int WM, int WN, int MF, int PRO, int EPI>
 static hipError_t launch_prec(const ConvArgs &a, hipStream_t st) {
     const bool fullc = a.cin % 16 == 0 && (a.c1 == 0 || a.c0 % 16 == 0);
@@ -1017,6 +1017,9 @@ hipError_t launch_conv(int mode, const ConvArgs &a, hipStream_t st) {
             return wide ? launch_prec<CONV_UP, 2, 2, 2, PRO_MASK, EPI_PLAIN>(a, st)
                         : launch_prec<CONV_UP, 1, 4, 2, PRO_MASK, EPI_PLAIN>(a, st);
         case CONV_P1:
+            if (a.pro == PRO_MASK && a.epi == EPI_PLAIN)        // training: res_conv / to_qkv / to_out and their data gradients (train.hip)
+                return wide ? launch_prec<CONV_P1, 2, 2, 2, PRO_MASK, EPI_PLAIN>(a, st)
+                            : launch_prec<CONV_P1, 1, 4, 2, PRO_MASK, EPI_PLAIN>(a, st);
             if (a.pro == PRO_MASK && a.epi == EPI_TAIL)
                 return wide ? launch_prec<CONV_P1, 2, 2, 2, PRO_MASK, EPI_TAIL>(a, st)
                             : launch_prec<CONV_P1, 1, 4, 2, PRO_MASK, EPI_TAIL>(a, st);

@@ -38,6 +38,8 @@ __global__ void pack_conv_kernel(const float *__restrict__ w, __bf16 *__restrict
             v = w[(((size_t)co * cin + ci) * 3 + stage) * 3 + tap];          // ky = stage, kx = tap
         } else if (mode == CONV_P1) {
             v = w[(size_t)co * cin + ci];
+        } else if (mode == CONV_P1 + 16) {
+            v = w[(size_t)ci * cout + co];          // data gradient of a 1x1 conv: the forward weight [cin'][cout'] transposed
         } else {   // CONV_UP: output phase (py, px); stage/tap pick the two contributing kernel rows/cols
             const int py = phase >> 1, px = phase & 1;
             const int ky = py == 0 ? (stage == 0 ? 1 : 3) : (stage == 0 ? 0 : 2);
@@ -55,8 +57,8 @@ __global__ void pack_conv_kernel(const float *__restrict__ w, __bf16 *__restrict
     dst[e_lo] = lo;
 }
 
-// mode CONV_C3 + 16: the transposed / flipped packing of a 3x3 conv for its data gradient (cin, cout are those of the
-// gradient convolution, i.e. swapped with respect to the forward weight tensor)
+// mode CONV_C3 + 16 / CONV_P1 + 16: the transposed (and, 3x3, flipped) packing of a conv for its data gradient (cin, cout are
+// those of the gradient convolution, i.e. swapped with respect to the forward weight tensor)
 hipError_t launch_pack_conv(int mode, const float *w, unsigned char *dst, int cin, int cout, hipStream_t st) {
     ConvGeom g = conv_geom(mode & 15, cin, cout);
     const int nkg = 2 * g.kch;

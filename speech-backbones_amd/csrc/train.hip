@@ -244,11 +244,54 @@ extern "C" int gtts_conv3x3_pack(const float *w, void *packed, int cin, int cout
 }
 
 // y = Conv2d_3x3(x * mask, packed W) + bias; x [B,cin,H,W], mask [B,W] (columns), y [B,cout,H,W].  cout % 64 == 0 (128 above 64).
-extern "C" int gtts_conv3x3_masked(const float *x, const float *mask, const void *packed, const float *bias, float *y, int B,
-                                   int cin, int cout, int H, int W, gtts_stream_t stream) {
+// x1 (nullable) / c0: the input is the channel concatenation of x [B,c0,H,W] and x1 [B,cin-c0,H,W] (c0 a multiple of 16), read
+// in place (torch.cat of the up path, diffusion.py:166)
+extern "C" int gtts_conv3x3_masked2(const float *x, const float *x1, int c0, const float *mask, const void *packed, const float *bias,
+                                    float *y, int B, int cin, int cout, int H, int W, gtts_stream_t stream) {
     if (!x || !mask || !packed || !bias || !y) return tfail(GTTS_E_NULL, "gtts_conv3x3_masked: null argument");
+    if (x1 && (c0 <= 0 || c0 >= cin || c0 % 16)) return tfail(GTTS_E_SHAPE, "gtts_conv3x3_masked: c0 must be a multiple of 16 inside (0, cin) (got %d of %d)", c0, cin);
     if (B <= 0 || cin <= 0 || cout <= 0 || H <= 0 || W <= 0) return tfail(GTTS_E_SHAPE, "gtts_conv3x3_masked: bad shape");
     if (cout % (cout > 64 ? 128 : 64) != 0) return tfail(GTTS_E_SHAPE, "gtts_conv3x3_masked: cout must be 64 or a multiple of 128 (got %d)", cout);
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src0 = x; a.src1 = x1 ? x1 : x; a.c0 = x1 ? c0 : cin; a.c1 = x1 ? cin - c0 : 0; a.cin = cin;
+    a.B = B; a.Hin = a.Hout = H; a.Win = a.Wout = W;
+    a.mask = mask; a.T = W; a.lvl_in = a.lvl_out = 0;
+    a.pro = PRO_MASK; a.epi = EPI_PLAIN;
+    a.w = (const unsigned char *)packed; a.w_bstride = 0;
+    a.bias = bias; a.bias_bstride = 0;
+    a.cout = cout; a.out = y; a.groups = 8; a.nsplit = 2;
+    const hipError_t e = launch_conv(CONV_C3, a, (hipStream_t)stream);
+    if (e != hipSuccess) return tfail(GTTS_E_HIP, "conv3x3 (cin %d, cout %d): %s", cin, cout, hipGetErrorString(e));
+    return GTTS_OK;
+}
+
+extern "C" int gtts_conv3x3_masked(const float *x, const float *mask, const void *packed, const float *bias, float *y, int B,
+                                   int cin, int cout, int H, int W, gtts_stream_t stream) {
+    return gtts_conv3x3_masked2(x, nullptr, 0, mask, packed, bias, y, B, cin, cout, H, W, stream);
+}
+
+// ---- 1x1 convolutions of the training path (res_conv, to_qkv, to_out: diffusion.py:70,87-88): forward and data gradient on
+// the inference CONV_P1 kernel (mask prologue, plain epilogue); the weight gradient is gtts_conv1x1_wgrad (train_wgrad.hip)
+extern "C" size_t gtts_conv1x1_packed_bytes(int cin, int cout) {
+    if (cin <= 0 || cout <= 0) return 0;
+    return (conv_packed_bytes(CONV_P1, cin, cout) + 255) / 256 * 256;
+}
+
+// transposed != 0: w is the FORWARD weight [forward cout = cin of this conv][forward cin = cout of this conv]
+extern "C" int gtts_conv1x1_pack(const float *w, void *packed, int cin, int cout, int transposed, gtts_stream_t stream) {
+    if (!w || !packed) return tfail(GTTS_E_NULL, "gtts_conv1x1_pack: null argument");
+    if (cin <= 0 || cout <= 0) return tfail(GTTS_E_SHAPE, "gtts_conv1x1_pack: bad shape");
+    TCHK(launch_pack_conv(transposed ? CONV_P1 + 16 : CONV_P1, w, (unsigned char *)packed, cin, cout, (hipStream_t)stream));
+    return GTTS_OK;
+}
+
+// y = Conv2d_1x1(x * mask, packed W) + bias; x [B,cin,H,W], mask [B,W] (columns), bias [cout], y [B,cout,H,W]
+extern "C" int gtts_conv1x1_masked(const float *x, const float *mask, const void *packed, const float *bias, float *y, int B,
+                                   int cin, int cout, int H, int W, gtts_stream_t stream) {
+    if (!x || !mask || !packed || !bias || !y) return tfail(GTTS_E_NULL, "gtts_conv1x1_masked: null argument");
+    if (B <= 0 || cin <= 0 || cout <= 0 || H <= 0 || W <= 0) return tfail(GTTS_E_SHAPE, "gtts_conv1x1_masked: bad shape");
+    if (cout % (cout > 64 ? 128 : 64) != 0) return tfail(GTTS_E_SHAPE, "gtts_conv1x1_masked: cout must be 64 or a multiple of 128 (got %d)", cout);
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.src0 = x; a.src1 = x; a.c0 = cin; a.c1 = 0; a.cin = cin;
@@ -258,8 +301,48 @@ extern "C" int gtts_conv3x3_masked(const float *x, const float *mask, const void
     a.w = (const unsigned char *)packed; a.w_bstride = 0;
     a.bias = bias; a.bias_bstride = 0;
     a.cout = cout; a.out = y; a.groups = 8; a.nsplit = 2;
-    const hipError_t e = launch_conv(CONV_C3, a, (hipStream_t)stream);
-    if (e != hipSuccess) return tfail(GTTS_E_HIP, "conv3x3 (cin %d, cout %d): %s", cin, cout, hipGetErrorString(e));
+    const hipError_t e = launch_conv(CONV_P1, a, (hipStream_t)stream);
+    if (e != hipSuccess) return tfail(GTTS_E_HIP, "conv1x1 (cin %d, cout %d): %s", cin, cout, hipGetErrorString(e));
+    return GTTS_OK;
+}
+
+// ---- Downsample (Conv2d 3x3, stride 2, pad 1: diffusion.py:28-34) and Upsample (ConvTranspose2d 4x4, stride 2, pad 1:
+// diffusion.py:19-25) of the training path on the inference kernels.  up = 0: w [cout][cin][3][3], y [B,cout,H/2,W/2];
+// up = 1: w [cin][cout][4][4] (ConvTranspose2d layout), y [B,cout,2H,2W].  The data gradient of Downsample IS an Upsample call:
+// a transposed 3x3 stride-2 convolution is the 4x4 one whose fourth kernel row and column are zero (same index map
+// y = 2 oy - 1 + ky), so the host packs the zero-padded forward weight with up = 1.
+extern "C" size_t gtts_conv_resample_packed_bytes(int cin, int cout, int up) {
+    if (cin <= 0 || cout <= 0) return 0;
+    return (conv_packed_bytes(up ? CONV_UP : CONV_DN, cin, cout) + 255) / 256 * 256;
+}
+
+extern "C" int gtts_conv_resample_pack(const float *w, void *packed, int cin, int cout, int up, gtts_stream_t stream) {
+    if (!w || !packed) return tfail(GTTS_E_NULL, "gtts_conv_resample_pack: null argument");
+    if (cin <= 0 || cout <= 0) return tfail(GTTS_E_SHAPE, "gtts_conv_resample_pack: bad shape");
+    TCHK(launch_pack_conv(up ? CONV_UP : CONV_DN, w, (unsigned char *)packed, cin, cout, (hipStream_t)stream));
+    return GTTS_OK;
+}
+
+// y = conv(x * mask) + bias; x [B,cin,H,W], mask [B,W] (columns of the INPUT).  H and W even for up = 0.
+extern "C" int gtts_conv_resample(const float *x, const float *mask, const void *packed, const float *bias, float *y, int B, int cin,
+                                  int cout, int H, int W, int up, gtts_stream_t stream) {
+    if (!x || !mask || !packed || !bias || !y) return tfail(GTTS_E_NULL, "gtts_conv_resample: null argument");
+    if (B <= 0 || cin <= 0 || cout <= 0 || H <= 0 || W <= 0) return tfail(GTTS_E_SHAPE, "gtts_conv_resample: bad shape");
+    if (!up && ((H | W) & 1)) return tfail(GTTS_E_SHAPE, "gtts_conv_resample: Downsample needs even H and W (got %d x %d)", H, W);
+    if (cin % 16 != 0 || cout % (cout > 64 ? 128 : 64) != 0)
+        return tfail(GTTS_E_SHAPE, "gtts_conv_resample: cin must be a multiple of 16 and cout 64 or a multiple of 128 (got %d, %d)", cin, cout);
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src0 = x; a.src1 = x; a.c0 = cin; a.c1 = 0; a.cin = cin;
+    a.B = B; a.Hin = H; a.Win = W;
+    a.Hout = up ? 2 * H : H / 2; a.Wout = up ? 2 * W : W / 2;
+    a.mask = mask; a.T = W; a.lvl_in = 0; a.lvl_out = 0;
+    a.pro = PRO_MASK; a.epi = EPI_PLAIN;
+    a.w = (const unsigned char *)packed; a.w_bstride = 0;
+    a.bias = bias; a.bias_bstride = 0;
+    a.cout = cout; a.out = y; a.groups = 8; a.nsplit = 2;
+    const hipError_t e = launch_conv(up ? CONV_UP : CONV_DN, a, (hipStream_t)stream);
+    if (e != hipSuccess) return tfail(GTTS_E_HIP, "conv resample (cin %d, cout %d, up %d): %s", cin, cout, up, hipGetErrorString(e));
     return GTTS_OK;
 }
 

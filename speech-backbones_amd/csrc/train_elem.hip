@@ -1,0 +1,159 @@
+// train_elem.hip -- the elementwise glue of the training path: ResnetBlock's residual add
+// (Grad-TTS/model/diffusion.py:77-78), the column mask of resampling inputs and gradients (diffusion.py:158,171), and the
+// final 64 -> 1 convolution with its two masks (diffusion.py:175-176).  All bound by HBM: float4 / plane-strided streams.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/gradtts_abi.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace gtts {
+
+// grid (B * C, ceil(HW / 1024)): out = a + b * mask[batch, w]   (a nullable: out = b * mask; mask nullable: out = a + b);
+// b may be a channel slice of a wider tensor (batch stride b_bstride floats)
+__global__ __launch_bounds__(256) void add_masked_kernel(const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ mask,
+                                                         float *__restrict__ out, int C, int HW, int W, size_t b_bstride) {
+    const int bc = blockIdx.x, bi = bc / C;
+    const size_t base = (size_t)bc * HW;
+    b += (size_t)bi * b_bstride + (size_t)(bc - bi * C) * HW - base;      // (b[base + i] below lands in the slice)
+    const float *mrow = mask ? mask + (size_t)bi * W : nullptr;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = blockIdx.y * 1024 + k * 256 + threadIdx.x;
+        if (i < HW) {
+            const float bv = mrow ? b[base + i] * mrow[i % W] : b[base + i];
+            out[base + i] = a ? a[base + i] + bv : bv;
+        }
+    }
+}
+
+// final_conv: out[b,p] = (sum_c w[c] x[b,c,p] m + bias) m,  m = mask[b, p % W]   (diffusion.py:175-176); grid (ceil(HW/256), B)
+__global__ __launch_bounds__(256) void final_conv_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                                                             const float *__restrict__ mask, float *__restrict__ out, int C, int HW, int W) {
+    const int p = blockIdx.x * 256 + threadIdx.x, bi = blockIdx.y;
+    if (p >= HW) return;
+    const float m = mask[(size_t)bi * W + p % W];
+    const float *px = x + (size_t)bi * C * HW + p;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) acc = fmaf(w[c], px[(size_t)c * HW], acc);
+    out[(size_t)bi * HW + p] = (acc * m + bias[0]) * m;
+}
+
+// dx[b,c,p] = w[c] dout[b,p] m^2; part[(b * nblk + blk)][c] = sum over the block's pixels of dout m^2 x[b,c,p] (c < C),
+// part[..][C] = sum of dout m (bias); grid (nblk = ceil(HW/256), B).  One pixel per thread, channel loop, LDS tree per channel
+// group would cost a barrier per channel: instead every wave reduces with shuffles and 4 waves combine through LDS.
+__global__ __launch_bounds__(256) void final_conv_bwd_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ mask,
+                                                             const float *__restrict__ dout, float *__restrict__ dx, float *__restrict__ part,
+                                                             int C, int HW, int W) {
+    extern __shared__ float s_w[];                 // [4 waves][C + 1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = blockIdx.x * 256 + tid, bi = blockIdx.y;
+    const bool ok = p < HW;
+    const float m = ok ? mask[(size_t)bi * W + p % W] : 0.f;
+    const float g = ok ? dout[(size_t)bi * HW + p] : 0.f;
+    const float gm2 = g * m * m;
+    const float *px = x + (size_t)bi * C * HW + p;
+    float *pd = dx + (size_t)bi * C * HW + p;
+    for (int c = 0; c <= C; ++c) {
+        float v;
+        if (c < C) {
+            const float xv = ok ? px[(size_t)c * HW] : 0.f;
+            if (ok) pd[(size_t)c * HW] = w[c] * gm2;
+            v = gm2 * xv;
+        } else {
+            v = g * m;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) s_w[wave * (C + 1) + c] = v;
+    }
+    __syncthreads();
+    for (int c = tid; c <= C; c += 256)
+        part[((size_t)bi * gridDim.x + blockIdx.x) * (C + 1) + c] = (s_w[c] + s_w[(C + 1) + c]) + (s_w[2 * (C + 1) + c] + s_w[3 * (C + 1) + c]);
+}
+
+// dw[c] (c < C), db = dw[C]: fixed-order sum of the partial records (fp64); one workgroup per channel
+__global__ __launch_bounds__(256) void final_conv_bwd_finish_kernel(const float *__restrict__ part, int nrec, int C, float *__restrict__ dw,
+                                                                    float *__restrict__ db) {
+    __shared__ double s_a[256];
+    const int c = blockIdx.x;
+    double t = 0.0;
+    for (int r = threadIdx.x; r < nrec; r += 256) t += (double)part[(size_t)r * (C + 1) + c];
+    s_a[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s_a[threadIdx.x] += s_a[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (c < C) dw[c] = (float)s_a[0];
+        else db[0] = (float)s_a[0];
+    }
+}
+
+}  // namespace gtts
+
+using namespace gtts;
+
+static int efail(int code, const char *fmt, ...) {       // text goes to gtts_last_error() (plan.hip)
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    return set_error(code, buf);
+}
+#define ECHK(expr)                                                                                                \
+    do {                                                                                                          \
+        hipError_t e_ = (expr);                                                                                   \
+        if (e_ != hipSuccess) return efail(GTTS_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// out = a + b * mask (a nullable: out = b * mask; mask nullable: out = a + b); a, b, out [B,C,H,W], mask [B,W]
+// b_cstride: channels of the tensor b is a slice of (0: b is contiguous [B,C,H,W])
+extern "C" int gtts_add_masked(const float *a, const float *b, const float *mask, float *out, int B, int C, int H, int W, int b_cstride,
+                               gtts_stream_t stream) {
+    if (!b || !out || (!a && !mask)) return efail(GTTS_E_NULL, "gtts_add_masked: null argument");
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (long)H * W >= (1l << 30)) return efail(GTTS_E_SHAPE, "gtts_add_masked: bad shape");
+    const int HW = H * W;
+    hipLaunchKernelGGL(add_masked_kernel, dim3(B * C, (HW + 1023) / 1024), dim3(256), 0, (hipStream_t)stream, a, b, mask, out, C, HW, W,
+                       (size_t)(b_cstride > 0 ? b_cstride : C) * HW);
+    ECHK(hipGetLastError());
+    return GTTS_OK;
+}
+
+// out [B,1,H,W] = (Conv2d_1x1(x * mask; w [C], bias [1]) ) * mask
+extern "C" int gtts_final_conv_forward(const float *x, const float *w, const float *bias, const float *mask, float *out, int B, int C,
+                                       int H, int W, gtts_stream_t stream) {
+    if (!x || !w || !bias || !mask || !out) return efail(GTTS_E_NULL, "gtts_final_conv_forward: null argument");
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return efail(GTTS_E_SHAPE, "gtts_final_conv_forward: bad shape");
+    const int HW = H * W;
+    hipLaunchKernelGGL(final_conv_fwd_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, w, bias, mask, out, C, HW, W);
+    ECHK(hipGetLastError());
+    return GTTS_OK;
+}
+
+extern "C" size_t gtts_final_conv_scratch_floats(int B, int C, int H, int W) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)B * ((H * W + 255) / 256) * (C + 1);
+}
+
+// dx [B,C,H,W], dw [C], db [1] of gtts_final_conv_forward given dout [B,1,H,W]
+extern "C" int gtts_final_conv_backward(const float *x, const float *w, const float *mask, const float *dout, float *dx, float *dw,
+                                        float *db, float *scratch, int B, int C, int H, int W, gtts_stream_t stream) {
+    if (!x || !w || !mask || !dout || !dx || !dw || !db || !scratch) return efail(GTTS_E_NULL, "gtts_final_conv_backward: null argument");
+    if (B <= 0 || C <= 0 || C > 1024 || H <= 0 || W <= 0) return efail(GTTS_E_SHAPE, "gtts_final_conv_backward: bad shape");
+    const int HW = H * W, nblk = (HW + 255) / 256;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(final_conv_bwd_kernel, dim3(nblk, B), dim3(256), (size_t)4 * (C + 1) * sizeof(float), st, x, w, mask, dout, dx, scratch, C,
+                       HW, W);
+    ECHK(hipGetLastError());
+    hipLaunchKernelGGL(final_conv_bwd_finish_kernel, dim3(C + 1), dim3(256), 0, st, scratch, B * nblk, C, dw, db);
+    ECHK(hipGetLastError());
+    return GTTS_OK;
+}

@@ -92,21 +92,22 @@ __device__ __forceinline__ void mish_and_grad(float z, float &m, float &dm) {
     dm = t + z * sg * (1.0f - t * t);
 }
 
-// grid (B * C, ceil(HW / 1024)): out = Mish(x_hat * gamma + beta) * mask[b, w]
+// grid (B * C, ceil(HW / 1024)): out = Mish(x_hat * gamma + beta) * mask[b, w] (+ tb[b, c])
 __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const float *__restrict__ y, const float *__restrict__ gamma,
                                                            const float *__restrict__ beta, const float *__restrict__ mask,
-                                                           const float *__restrict__ stats, float *__restrict__ out, int C, int HW,
-                                                           int W, int cpg) {
+                                                           const float *__restrict__ stats, const float *__restrict__ tb,
+                                                           float *__restrict__ out, int C, int HW, int W, int cpg) {
     const int bc = blockIdx.x, b = bc / C, c = bc - b * C, g = c / cpg;
     const float mean = stats[2 * (b * (C / cpg) + g)], rstd = stats[2 * (b * (C / cpg) + g) + 1];
     const float sc = rstd * gamma[c], sh = beta[c] - mean * sc;
+    const float tbv = tb ? tb[bc] : 0.f;          // ResnetBlock's time bias, added AFTER the mask (diffusion.py:75-76)
     const float *p = y + (size_t)bc * HW;
     float *q = out + (size_t)bc * HW;
     const float *mrow = mask + (size_t)b * W;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i = blockIdx.y * 1024 + k * 256 + threadIdx.x;
-        if (i < HW) q[i] = mish_f(p[i] * sc + sh) * mrow[i % W];
+        if (i < HW) q[i] = mish_f(p[i] * sc + sh) * mrow[i % W] + tbv;
     }
 }
 
@@ -114,15 +115,16 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const float *__restric
 __global__ __launch_bounds__(256) void gn_mish_bwd_reduce_kernel(const float *__restrict__ dout, const float *__restrict__ y,
                                                                   const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                   const float *__restrict__ mask, const float *__restrict__ stats,
-                                                                  float *__restrict__ ws, int C, int HW, int W, int cpg) {
+                                                                  float *__restrict__ ws, float *__restrict__ dtb, int C, int HW, int W,
+                                                                  int cpg) {
     __shared__ double s_a[256], s_b[256];
     const int bc = blockIdx.x, b = bc / C, c = bc - b * C, g = c / cpg;
     const float mean = stats[2 * (b * (C / cpg) + g)], rstd = stats[2 * (b * (C / cpg) + g) + 1];
     const float ga = gamma[c], be = beta[c];
     const float *p = y + (size_t)bc * HW, *d = dout + (size_t)bc * HW;
     const float *mrow = mask + (size_t)b * W;
-    float s1 = 0.f, s2 = 0.f;
-    double d1 = 0.0, d2 = 0.0;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    double d1 = 0.0, d2 = 0.0, d3 = 0.0;
     int k = 0;
     for (int i = threadIdx.x; i < HW; i += 256) {
         const float xh = (p[i] - mean) * rstd;
@@ -131,17 +133,24 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_reduce_kernel(const float *__
         const float dz = d[i] * mrow[i % W] * dm;
         s1 += dz;
         s2 += dz * xh;
+        s3 += d[i];
         if (++k == 64) {
-            d1 += (double)s1; d2 += (double)s2;
-            s1 = 0.f; s2 = 0.f; k = 0;
+            d1 += (double)s1; d2 += (double)s2; d3 += (double)s3;
+            s1 = 0.f; s2 = 0.f; s3 = 0.f; k = 0;
         }
     }
     d1 += (double)s1;
     d2 += (double)s2;
+    d3 += (double)s3;
     block_sum2(d1, d2, s_a, s_b);
     if (threadIdx.x == 0) {
         ws[2 * bc] = (float)d1;
         ws[2 * bc + 1] = (float)d2;
+    }
+    if (dtb) {          // gradient of the time bias: the plain sum of d out over the plane
+        double z = 0.0;
+        block_sum2(d3, z, s_a, s_b);
+        if (threadIdx.x == 0) dtb[bc] = (float)d3;
     }
 }
 
@@ -220,8 +229,10 @@ static int norm_shape_ok(int B, int C, int H, int W, int groups) {
     return B > 0 && C > 0 && H > 0 && W > 0 && groups > 0 && C % groups == 0 && (long)H * W < (1l << 30);
 }
 
-extern "C" int gtts_gn_mish_forward(const float *y, const float *gamma, const float *beta, const float *mask, float *out,
-                                    float *stats, int B, int C, int H, int W, int groups, float eps, gtts_stream_t stream) {
+// tb (nullable): [B][C] bias added after the mask (ResnetBlock's time embedding term, diffusion.py:75-76)
+extern "C" int gtts_gn_mish_forward_tb(const float *y, const float *gamma, const float *beta, const float *mask, const float *tb,
+                                       float *out, float *stats, int B, int C, int H, int W, int groups, float eps,
+                                       gtts_stream_t stream) {
     if (!y || !gamma || !beta || !mask || !out || !stats) return nfail(GTTS_E_NULL, "gtts_gn_mish_forward: null argument");
     if (!norm_shape_ok(B, C, H, W, groups)) return nfail(GTTS_E_SHAPE, "gtts_gn_mish_forward: bad shape B=%d C=%d H=%d W=%d groups=%d", B, C, H, W, groups);
     const int HW = H * W, cpg = C / groups;
@@ -232,9 +243,14 @@ extern "C" int gtts_gn_mish_forward(const float *y, const float *gamma, const fl
     hipLaunchKernelGGL(gn_stats_finish_kernel, dim3((B * groups + 255) / 256), dim3(256), 0, st, partial, stats, B * groups,
                        1.0 / ((double)cpg * HW), eps);
     NCHK(hipGetLastError());
-    hipLaunchKernelGGL(gn_mish_fwd_kernel, dim3(B * C, (HW + 1023) / 1024), dim3(256), 0, st, y, gamma, beta, mask, stats, out, C, HW, W, cpg);
+    hipLaunchKernelGGL(gn_mish_fwd_kernel, dim3(B * C, (HW + 1023) / 1024), dim3(256), 0, st, y, gamma, beta, mask, stats, tb, out, C, HW, W, cpg);
     NCHK(hipGetLastError());
     return GTTS_OK;
+}
+
+extern "C" int gtts_gn_mish_forward(const float *y, const float *gamma, const float *beta, const float *mask, float *out,
+                                    float *stats, int B, int C, int H, int W, int groups, float eps, gtts_stream_t stream) {
+    return gtts_gn_mish_forward_tb(y, gamma, beta, mask, nullptr, out, stats, B, C, H, W, groups, eps, stream);
 }
 
 extern "C" size_t gtts_gn_mish_stats_floats(int B, int groups) {
@@ -243,9 +259,10 @@ extern "C" size_t gtts_gn_mish_stats_floats(int B, int groups) {
 
 extern "C" size_t gtts_gn_mish_scratch_bytes(int B, int C) { return B > 0 && C > 0 ? (size_t)B * C * 2 * 4 * 2 : 0; }
 
-extern "C" int gtts_gn_mish_backward(const float *dout, const float *y, const float *gamma, const float *beta, const float *mask,
-                                     const float *stats, float *dy, float *dgamma, float *dbeta, void *scratch, int B, int C, int H,
-                                     int W, int groups, gtts_stream_t stream) {
+// dtb (nullable): [B][C] gradient of the time bias
+extern "C" int gtts_gn_mish_backward_tb(const float *dout, const float *y, const float *gamma, const float *beta, const float *mask,
+                                        const float *stats, float *dy, float *dgamma, float *dbeta, float *dtb, void *scratch, int B,
+                                        int C, int H, int W, int groups, gtts_stream_t stream) {
     if (!dout || !y || !gamma || !beta || !mask || !stats || !dy || !dgamma || !dbeta || !scratch)
         return nfail(GTTS_E_NULL, "gtts_gn_mish_backward: null argument");
     if (!norm_shape_ok(B, C, H, W, groups)) return nfail(GTTS_E_SHAPE, "gtts_gn_mish_backward: bad shape B=%d C=%d H=%d W=%d groups=%d", B, C, H, W, groups);
@@ -253,7 +270,7 @@ extern "C" int gtts_gn_mish_backward(const float *dout, const float *y, const fl
     hipStream_t st = (hipStream_t)stream;
     float *ws = (float *)scratch;                 // [B][C][2]
     float *coef = ws + (size_t)B * C * 2;         // [B][groups][2]  (fits: groups <= C)
-    hipLaunchKernelGGL(gn_mish_bwd_reduce_kernel, dim3(B * C), dim3(256), 0, st, dout, y, gamma, beta, mask, stats, ws, C, HW, W, cpg);
+    hipLaunchKernelGGL(gn_mish_bwd_reduce_kernel, dim3(B * C), dim3(256), 0, st, dout, y, gamma, beta, mask, stats, ws, dtb, C, HW, W, cpg);
     NCHK(hipGetLastError());
     hipLaunchKernelGGL(gn_mish_bwd_finish_kernel, dim3(1), dim3(256), 0, st, ws, gamma, dgamma, dbeta, coef, B, C, cpg,
                        1.0 / ((double)cpg * HW));
@@ -262,4 +279,10 @@ extern "C" int gtts_gn_mish_backward(const float *dout, const float *y, const fl
                        dy, C, HW, W, cpg);
     NCHK(hipGetLastError());
     return GTTS_OK;
+}
+
+extern "C" int gtts_gn_mish_backward(const float *dout, const float *y, const float *gamma, const float *beta, const float *mask,
+                                     const float *stats, float *dy, float *dgamma, float *dbeta, void *scratch, int B, int C, int H,
+                                     int W, int groups, gtts_stream_t stream) {
+    return gtts_gn_mish_backward_tb(dout, y, gamma, beta, mask, stats, dy, dgamma, dbeta, nullptr, scratch, B, C, H, W, groups, stream);
 }

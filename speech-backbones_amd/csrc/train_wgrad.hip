@@ -24,16 +24,12 @@
 #include "common.h"
 #include "kernels.h"
 
-// WG_PF=1: prefetch the x items of chunk c + 1 in registers across the MFMAs of chunk c.  Measured slower (212 vs 201 us on the
-// 256 -> 256 layer): with 144 accumulator registers the 40 prefetch registers push the kernel into scratch.  Off.
-#ifndef WG_PF
-#define WG_PF 0
-#endif
-
 namespace gtts {
 
 struct Wgrad2Args {
-    const float *x;        // [B][cin][H][W]
+    const float *x;        // [B][cin][H][W], or the first c0 channels of a concatenated input ...
+    const float *x1;       // ... whose other cin - c0 channels are [B][cin - c0][H][W] here (nullptr: one source); c0 % 64 == 0
+    int c0;
     const float *mask;     // [B][W]
     const float *dy;       // [B][cout][H][W]
     float *part;           // [nslice][tiles][9][64 co][64 ci]
@@ -63,62 +59,123 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4 &hi, u32x4 &lo
     lo = __builtin_bit_cast(u32x4, vl);
 }
 
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad2_kernel(const Wgrad2Args a) {
+// Wave-specialised: waves 0-3 are CONSUMERS (one 32 co x 32 ci x 9 tap accumulator block each: fragment reads, the
+// alignbit shifts and MFMAs only), waves 4-7 are PRODUCERS (global loads, mask, hi / lo split, LDS writes, bias sums).  The LDS
+// tile is double-buffered and one barrier per chunk hands a buffer over: the producers stage chunk c + 1 (and have the loads
+// of chunk c + 2 in flight across the barrier) while the consumers multiply chunk c.  (The uniform-wave form of round 2 --
+// every wave loading, splitting, then multiplying between two barriers -- exposed the load latency and the split VALU work
+// once per chunk: 190 us per launch where the MFMAs need 45.)
+__global__ __launch_bounds__(512, 1) void conv3x3_wgrad2_kernel(const Wgrad2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
-    u32x4 *s_dyh = reinterpret_cast<u32x4 *>(wg_smem), *s_dyl = s_dyh + 64 * DY_STRIDE;
-    u32x4 *s_xh = s_dyl + 64 * DY_STRIDE, *s_xl = s_xh + 64 * X_STRIDE;
+    constexpr int BUF16 = 2 * 64 * DY_STRIDE + 2 * 64 * X_STRIDE;      // 16-byte slots of one buffer
+    u32x4 *s_base = reinterpret_cast<u32x4 *>(wg_smem);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, kg = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
     const int ncit = a.cin / 64;
     const int tiles = ncit * (a.cout / 64);
     const int tile = blockIdx.x % tiles, slice = blockIdx.x / tiles;
     const int co0 = (tile / ncit) * 64, ci0 = (tile % ncit) * 64;
     const size_t HW = (size_t)a.H * a.W;
-
-    f32x16 acc[3][3];
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ky][kx][r] = 0.f;
-
-    float bsum[2] = {0.f, 0.f};            // bias gradient: this thread's dy items belong to co = (tid >> 3) + 32 k
     const int per = (a.nchunk + a.nslice - 1) / a.nslice;
     const int c_begin = slice * per, c_end = min(a.nchunk, c_begin + per);
-    // Global loads: 16-byte buffer loads at dword-aligned offsets (rows of an NCHW plane start anywhere), issued for chunk
-    // c + 1 right before the MFMAs of chunk c and consumed after them (registers: 4 + 2 items of 8 floats, 2 edge values,
-    // 8 mask values).  Columns past the row end alias the next row and are zeroed by selects; rows outside the image and
-    // whole items past the tensor read offset 0 and are zeroed the same way.
-    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)((size_t)a.B * a.cin * HW * 4), 0x00020000);
+
+    if (wave < 4) {
+        // =============================================================================== CONSUMERS
+        const int l31 = lane & 31, kg = lane >> 5;
+        const int wm = wave >> 1, wn = wave & 1;
+        f32x16 acc[3][3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ky][kx][r] = 0.f;
+        // (bottom-tested by hand: with the exit test at the top hipcc copies all 144 accumulator registers around the loop)
+        if (c_begin < c_end) {
+            int ch = c_begin;
+            do {
+                __syncthreads();                    // chunk ch is staged; the producers may overwrite the other buffer
+                const u32x4 *s_dyh = s_base + ((ch - c_begin) & 1) * BUF16, *s_dyl = s_dyh + 64 * DY_STRIDE;
+                const u32x4 *s_xh = s_dyl + 64 * DY_STRIDE, *s_xl = s_xh + 64 * X_STRIDE;
+                // ---- 4 k-steps of 16 pixels: (row r, column half cb); lane's block = 2 cb + kg
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int r = ks >> 1, blk = (ks & 1) * 2 + kg;
+                    const int ai = (wm * 32 + l31) * DY_STRIDE + r * 4 + blk;
+                    const bf16x8 Ah = __builtin_bit_cast(bf16x8, s_dyh[ai]), Al = __builtin_bit_cast(bf16x8, s_dyl[ai]);
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const int rr = r + ky, ci = wn * 32 + l31;
+                        const int bi = ci * X_STRIDE + rr * X_ROW + 1 + blk;
+                        const unsigned *xh32 = reinterpret_cast<const unsigned *>(s_xh), *xl32 = reinterpret_cast<const unsigned *>(s_xl);
+                        const u32x4 dh = s_xh[bi], dl = s_xl[bi];
+                        // P: dword holding the pixel left of the block in its HIGH half; N: dword holding the pixel right of it in its LOW half
+                        const unsigned Ph = xh32[bi * 4 - 1], Pl = xl32[bi * 4 - 1], Nh = xh32[bi * 4 + 4], Nl = xl32[bi * 4 + 4];
+                        // shifted fragments: (e[-1], e0) (e1, e2) (e3, e4) (e5, e6)   and   (e1, e2) (e3, e4) (e5, e6) (e7, e[8])
+                        const unsigned m1h = __builtin_amdgcn_alignbit(dh[1], dh[0], 16), m2h = __builtin_amdgcn_alignbit(dh[2], dh[1], 16),
+                                       m3h = __builtin_amdgcn_alignbit(dh[3], dh[2], 16);
+                        const unsigned m1l = __builtin_amdgcn_alignbit(dl[1], dl[0], 16), m2l = __builtin_amdgcn_alignbit(dl[2], dl[1], 16),
+                                       m3l = __builtin_amdgcn_alignbit(dl[3], dl[2], 16);
+                        u32x4 b0h, b0l, b2h, b2l;
+                        b0h[0] = __builtin_amdgcn_alignbit(dh[0], Ph, 16); b0h[1] = m1h; b0h[2] = m2h; b0h[3] = m3h;
+                        b0l[0] = __builtin_amdgcn_alignbit(dl[0], Pl, 16); b0l[1] = m1l; b0l[2] = m2l; b0l[3] = m3l;
+                        b2h[0] = m1h; b2h[1] = m2h; b2h[2] = m3h; b2h[3] = __builtin_amdgcn_alignbit(Nh, dh[3], 16);
+                        b2l[0] = m1l; b2l[1] = m2l; b2l[2] = m3l; b2l[3] = __builtin_amdgcn_alignbit(Nl, dl[3], 16);
+                        const bf16x8 Bh[3] = {__builtin_bit_cast(bf16x8, b0h), __builtin_bit_cast(bf16x8, dh), __builtin_bit_cast(bf16x8, b2h)};
+                        const bf16x8 Bl[3] = {__builtin_bit_cast(bf16x8, b0l), __builtin_bit_cast(bf16x8, dl), __builtin_bit_cast(bf16x8, b2l)};
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            acc[ky][kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh[kx], acc[ky][kx], 0, 0, 0);
+                            acc[ky][kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl[kx], acc[ky][kx], 0, 0, 0);
+                            acc[ky][kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh[kx], acc[ky][kx], 0, 0, 0);
+                        }
+                    }
+                }
+            } while (++ch < c_end);
+        }
+        // ---- partial tile: D[m = co][n = ci]; lane (l31 = ci, kg) holds rows (rg&3) + 8 (rg>>2) + 4 kg
+        float *out = a.part + ((size_t)slice * tiles + tile) * (9 * 64 * 64);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int co = wm * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kg;
+                    out[((ky * 3 + kx) * 64 + co) * 64 + wn * 32 + l31] = acc[ky][kx][rg];
+                }
+        return;
+    }
+    // =================================================================================== PRODUCERS
+    const int ptid = tid - 256;
+    float bsum[2] = {0.f, 0.f};            // bias gradient: this thread's dy items belong to co = (ptid >> 3) + 32 k
+    // Global loads: 16-byte buffer loads at dword-aligned offsets (rows of an NCHW plane start anywhere).  Columns past the
+    // row end alias the next row and are zeroed by selects; rows outside the image and whole items past the tensor read
+    // offset 0 and are zeroed the same way.
+    // the workgroup's 64 input channels lie in one source (torch.cat of the up path read in place: diffusion.py:166)
+    const bool second = a.x1 != nullptr && ci0 >= a.c0;
+    const float *xsrc = second ? a.x1 : a.x;
+    const int xc = a.x1 == nullptr ? a.cin : (second ? a.cin - a.c0 : a.c0), xc0 = second ? ci0 - a.c0 : ci0;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xsrc), 0, (int)((size_t)a.B * xc * HW * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.dy), 0, (int)((size_t)a.B * a.cout * HW * 4), 0x00020000);
     u32x4 xr[4][2], dr[2][2];
     float er[2], mk[8];
-    // x (the bulk) and the mask values are prefetched across the MFMAs; dy and the edge columns are loaded at the top of the
-    // iteration and consumed after the x items have been split -- their latency hides behind that work without holding
-    // registers through the MFMA phase (the 144 accumulator registers leave room for one of the two)
-    auto issue_x = [&](int ch) {
+    auto issue = [&](int ch) {
         const int cx = ch % a.ncx, cy = (ch / a.ncx) % a.ncy, b = ch / (a.ncx * a.ncy);
         const int x0 = cx * 32, y0 = cy * 2;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) mk[i] = a.mask[(size_t)b * a.W + min(x0 + 8 * (tid & 3) + i, a.W - 1)];
+        for (int i = 0; i < 8; ++i) mk[i] = a.mask[(size_t)b * a.W + min(x0 + 8 * (ptid & 3) + i, a.W - 1)];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int item = tid + 256 * k, blk = item & 3, rr = (item >> 2) & 3, ci = item >> 4;
+            const int item = ptid + 256 * k, blk = item & 3, rr = (item >> 2) & 3, ci = item >> 4;
             const int y = min(max(y0 - 1 + rr, 0), a.H - 1), px = min(x0 + 8 * blk, a.W - 1);
-            const int off = (int)((((size_t)b * a.cin + ci0 + ci) * HW + (size_t)y * a.W + px) * 4);
+            const int off = (int)((((size_t)b * xc + xc0 + ci) * HW + (size_t)y * a.W + px) * 4);
             xr[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0);
             xr[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rsx, off + 16, 0, 0);
         }
-    };
-    auto issue_d = [&](int ch) {
-        const int cx = ch % a.ncx, cy = (ch / a.ncx) % a.ncy, b = ch / (a.ncx * a.ncy);
-        const int x0 = cx * 32, y0 = cy * 2;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int item = tid + 256 * k, blk = item & 3, r = (item >> 2) & 1, co = item >> 3;
+            const int item = ptid + 256 * k, blk = item & 3, r = (item >> 2) & 1, co = item >> 3;
             const int y = min(y0 + r, a.H - 1), px = min(x0 + 8 * blk, a.W - 1);
             const int off = (int)((((size_t)b * a.cout + co0 + co) * HW + (size_t)y * a.W + px) * 4);
             dr[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rsd, off, 0, 0);
@@ -126,32 +183,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad2_kernel(const Wgrad2Args
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int item = tid + 256 * k, side = item & 1, rr = (item >> 1) & 3, ci = item >> 3;
+            const int item = ptid + 256 * k, side = item & 1, rr = (item >> 1) & 3, ci = item >> 3;
             const int y = y0 - 1 + rr, px = side ? x0 + 32 : x0 - 1;
             const bool ok = y >= 0 && y < a.H && px >= 0 && px < a.W;
             const int pc = min(max(px, 0), a.W - 1);
-            const float t = a.x[((size_t)b * a.cin + ci0 + ci) * HW + (size_t)(ok ? y : 0) * a.W + pc] * a.mask[(size_t)b * a.W + pc];
+            const float t = xsrc[((size_t)b * xc + xc0 + ci) * HW + (size_t)(ok ? y : 0) * a.W + pc] * a.mask[(size_t)b * a.W + pc];
             er[k] = ok ? t : 0.f;
         }
     };
-    // (bottom-tested by hand: with the exit test at the top hipcc copies all 144 accumulator registers around the loop)
-    if (c_begin < c_end) {
-#if WG_PF
-    issue_x(c_begin);
-#endif
-    int ch = c_begin;
-    do {
+    if (c_begin < c_end) issue(c_begin);
+    for (int ch = c_begin; ch < c_end; ++ch) {
         const int cx = ch % a.ncx, cy = (ch / a.ncx) % a.ncy;
         const int x0 = cx * 32, y0 = cy * 2;
-        __syncthreads();                    // the previous chunk's fragment reads are done
-#if !WG_PF
-        issue_x(ch);
-#endif
-        issue_d(ch);
+        u32x4 *s_dyh = s_base + ((ch - c_begin) & 1) * BUF16, *s_dyl = s_dyh + 64 * DY_STRIDE;
+        u32x4 *s_xh = s_dyl + 64 * DY_STRIDE, *s_xl = s_xh + 64 * X_STRIDE;
         // ---- x * mask: 1024 main items (ci, row 0..3 = image rows y0-1..y0+2, block) -> bf16 hi / lo
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int item = tid + 256 * k, blk = item & 3, rr = (item >> 2) & 3, ci = item >> 4;
+            const int item = ptid + 256 * k, blk = item & 3, rr = (item >> 2) & 3, ci = item >> 4;
             const int y = y0 - 1 + rr, px = x0 + 8 * blk;
             const bool rowok = y >= 0 && y < a.H;
             float v[8];
@@ -169,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad2_kernel(const Wgrad2Args
         // ---- dy: 512 items (co, row, block)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int item = tid + 256 * k, blk = item & 3, r = (item >> 2) & 1, co = item >> 3;
+            const int item = ptid + 256 * k, blk = item & 3, r = (item >> 2) & 1, co = item >> 3;
             const int y = y0 + r, px = x0 + 8 * blk;
             float v[8];
 #pragma unroll
@@ -187,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad2_kernel(const Wgrad2Args
         // ---- the two edge columns (x0 - 1 -> high half, x0 + 32 -> low half of the stored dword): 512 items
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int item = tid + 256 * k, side = item & 1, rr = (item >> 1) & 3, ci = item >> 3;
+            const int item = ptid + 256 * k, side = item & 1, rr = (item >> 1) & 3, ci = item >> 3;
             __bf16 h, l;
             split_bf16(er[k], h, l);
             const unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, h), lb = (unsigned)__builtin_bit_cast(unsigned short, l);
@@ -195,57 +244,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad2_kernel(const Wgrad2Args
             reinterpret_cast<unsigned *>(s_xh)[di] = side ? hb : hb << 16;
             reinterpret_cast<unsigned *>(s_xl)[di] = side ? lb : lb << 16;
         }
-        __syncthreads();
-#if WG_PF
-        issue_x(min(ch + 1, c_end - 1));    // unconditional prefetch behind the MFMAs (the last one is never used)
-#endif
-        // ---- 4 k-steps of 16 pixels: (row r, column half cb); lane's block = 2 cb + kg
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int r = ks >> 1, blk = (ks & 1) * 2 + kg;
-            const int ai = (wm * 32 + l31) * DY_STRIDE + r * 4 + blk;
-            const bf16x8 Ah = __builtin_bit_cast(bf16x8, s_dyh[ai]), Al = __builtin_bit_cast(bf16x8, s_dyl[ai]);
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int rr = r + ky, ci = wn * 32 + l31;
-                const int bi = ci * X_STRIDE + rr * X_ROW + 1 + blk;
-                const unsigned *xh32 = reinterpret_cast<const unsigned *>(s_xh), *xl32 = reinterpret_cast<const unsigned *>(s_xl);
-                const u32x4 dh = s_xh[bi], dl = s_xl[bi];
-                // P: dword holding the pixel left of the block in its HIGH half; N: dword holding the pixel right of it in its LOW half
-                const unsigned Ph = xh32[bi * 4 - 1], Pl = xl32[bi * 4 - 1], Nh = xh32[bi * 4 + 4], Nl = xl32[bi * 4 + 4];
-                // shifted fragments: (e[-1], e0) (e1, e2) (e3, e4) (e5, e6)   and   (e1, e2) (e3, e4) (e5, e6) (e7, e[8])
-                const unsigned m1h = __builtin_amdgcn_alignbit(dh[1], dh[0], 16), m2h = __builtin_amdgcn_alignbit(dh[2], dh[1], 16),
-                               m3h = __builtin_amdgcn_alignbit(dh[3], dh[2], 16);
-                const unsigned m1l = __builtin_amdgcn_alignbit(dl[1], dl[0], 16), m2l = __builtin_amdgcn_alignbit(dl[2], dl[1], 16),
-                               m3l = __builtin_amdgcn_alignbit(dl[3], dl[2], 16);
-                u32x4 b0h, b0l, b2h, b2l;
-                b0h[0] = __builtin_amdgcn_alignbit(dh[0], Ph, 16); b0h[1] = m1h; b0h[2] = m2h; b0h[3] = m3h;
-                b0l[0] = __builtin_amdgcn_alignbit(dl[0], Pl, 16); b0l[1] = m1l; b0l[2] = m2l; b0l[3] = m3l;
-                b2h[0] = m1h; b2h[1] = m2h; b2h[2] = m3h; b2h[3] = __builtin_amdgcn_alignbit(Nh, dh[3], 16);
-                b2l[0] = m1l; b2l[1] = m2l; b2l[2] = m3l; b2l[3] = __builtin_amdgcn_alignbit(Nl, dl[3], 16);
-                const bf16x8 Bh[3] = {__builtin_bit_cast(bf16x8, b0h), __builtin_bit_cast(bf16x8, dh), __builtin_bit_cast(bf16x8, b2h)};
-                const bf16x8 Bl[3] = {__builtin_bit_cast(bf16x8, b0l), __builtin_bit_cast(bf16x8, dl), __builtin_bit_cast(bf16x8, b2l)};
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    acc[ky][kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh[kx], acc[ky][kx], 0, 0, 0);
-                    acc[ky][kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl[kx], acc[ky][kx], 0, 0, 0);
-                    acc[ky][kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh[kx], acc[ky][kx], 0, 0, 0);
-                }
-            }
-        }
-    } while (++ch < c_end);
+        if (ch + 1 < c_end) issue(ch + 1);      // in flight across the barrier wait
+        __syncthreads();                        // chunk ch handed over; the consumers are done with the buffer of chunk ch - 1
     }
-    // ---- partial tile: D[m = co][n = ci]; lane (l31 = ci, kg) holds rows (rg&3) + 8 (rg>>2) + 4 kg
-    float *out = a.part + ((size_t)slice * tiles + tile) * (9 * 64 * 64);
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-            for (int rg = 0; rg < 16; ++rg) {
-                const int co = wm * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kg;
-                out[((ky * 3 + kx) * 64 + co) * 64 + wn * 32 + l31] = acc[ky][kx][rg];
-            }
     if (a.dbpart && ci0 == 0) {
         // the 8 threads (row, block) of a co are consecutive lanes: fixed-order butterfly, lane 0 of each octet publishes
 #pragma unroll
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad2_kernel(const Wgrad2Args
             v += __shfl_xor(v, 1, 64);
             v += __shfl_xor(v, 2, 64);
             v += __shfl_xor(v, 4, 64);
-            if ((tid & 7) == 0) a.dbpart[(size_t)slice * a.cout + co0 + (tid >> 3) + 32 * k] = v;
+            if ((ptid & 7) == 0) a.dbpart[(size_t)slice * a.cout + co0 + (ptid >> 3) + 32 * k] = v;
         }
     }
 }
@@ -264,10 +265,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad2_kernel(const Wgrad2Args
 // combined through LDS in a fixed order.  The last workgroups of the grid reduce the bias partials the same way.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, const float *__restrict__ dbpart,
                                                            float *__restrict__ dw, float *__restrict__ db, int cin, int cout,
-                                                           int nslice) {
+                                                           int nslice, int taps) {
     __shared__ float s_red[8][32];
     const int ncit = cin / 64, tiles = ncit * (cout / 64);
-    const size_t tile_elems = 9 * 64 * 64, total = (size_t)tiles * tile_elems;
+    const size_t tile_elems = (size_t)taps * 64 * 64, total = (size_t)tiles * tile_elems;
     const int e32 = threadIdx.x & 31, sg = threadIdx.x >> 5;
     const size_t idx = (size_t)blockIdx.x * 32 + e32;
     const bool is_w = idx < total;                       // (total is a multiple of 32: a workgroup is all-weights or all-bias)
@@ -296,11 +297,126 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
         if (is_w) {
             const int tile = (int)(idx / tile_elems), e = (int)(idx % tile_elems);
             const int tap = e / 4096, co = (tile / ncit) * 64 + (e >> 6) % 64, ci = (tile % ncit) * 64 + (e & 63);
-            dw[((size_t)co * cin + ci) * 9 + tap] = t;
+            dw[((size_t)co * cin + ci) * taps + tap] = t;
         } else if (db && dbpart && bco < (size_t)cout) {
             db[bco] = t;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------- 1x1 convolutions
+// dW[co][ci] = sum_{b,p} dy[b,co,p] * (x * mask)[b,ci,p]  (res_conv, to_qkv, to_out: diffusion.py:70,87-88) -- the same
+// pixel-contraction GEMM without taps: a chunk is 64 consecutive pixels of one sample's flattened H x W plane, the workgroup
+// tile 64 co x 64 ci (four waves, one 32 x 32 accumulator each), split bf16 hi / lo planes in LDS ([channel][8-pixel block],
+// odd channel stride), the loads of chunk c + 1 in flight across the MFMAs of chunk c, slices over pixels reduced by
+// wgrad_reduce_kernel in a fixed order.
+struct Wgrad1Args {
+    const float *x;        // [B][cin][HW]
+    const float *mask;     // [B][W] or nullptr
+    const float *dy;       // [B][cout][HW]
+    float *part;           // [nslice][tiles][64 co][64 ci]
+    float *dbpart;         // [nslice][cout] or nullptr
+    int B, cin, cout, HW, W;
+    int cps;               // chunks per sample: ceil(HW / 64)
+    int nchunk, nslice;
+};
+
+__global__ __launch_bounds__(256, 2) void conv1x1_wgrad_kernel(const Wgrad1Args a) {
+    __shared__ __attribute__((aligned(16))) u32x4 s_dy[2][64 * DY_STRIDE], s_x[2][64 * DY_STRIDE];     // [hi | lo][channel][8 blocks + pad]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ncit = a.cin / 64;
+    const int tiles = ncit * (a.cout / 64);
+    const int tile = blockIdx.x % tiles, slice = blockIdx.x / tiles;
+    const int co0 = (tile / ncit) * 64, ci0 = (tile % ncit) * 64;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bsum[2] = {0.f, 0.f};
+    const int per = (a.nchunk + a.nslice - 1) / a.nslice;
+    const int c_begin = slice * per, c_end = min(a.nchunk, c_begin + per);
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)((size_t)a.B * a.cin * a.HW * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.dy), 0, (int)((size_t)a.B * a.cout * a.HW * 4), 0x00020000);
+    u32x4 xr[2][2], dr[2][2];
+    auto issue = [&](int ch) {
+        const int b = ch / a.cps, p0 = (ch % a.cps) * 64;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int item = tid + 256 * k, blk = item & 7, c = item >> 3;
+            const int p = min(p0 + 8 * blk, a.HW - 1);
+            const int ox = (int)((((size_t)b * a.cin + ci0 + c) * a.HW + p) * 4), od = (int)((((size_t)b * a.cout + co0 + c) * a.HW + p) * 4);
+            xr[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rsx, ox, 0, 0);
+            xr[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rsx, ox + 16, 0, 0);
+            dr[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rsd, od, 0, 0);
+            dr[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rsd, od + 16, 0, 0);
+        }
+    };
+    if (c_begin < c_end) issue(c_begin);
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        const int b = ch / a.cps, p0 = (ch % a.cps) * 64;
+        __syncthreads();                    // the previous chunk's fragment reads are done
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int item = tid + 256 * k, blk = item & 7, c = item >> 3;
+            const int p = p0 + 8 * blk;
+            float vx[8], vd[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned wx = xr[k][i >> 2][i & 3], wd = dr[k][i >> 2][i & 3];
+                const bool ok = p + i < a.HW;
+                const float m = a.mask ? a.mask[(size_t)b * a.W + (ok ? (p + i) % a.W : 0)] : 1.f;
+                vx[i] = ok ? __builtin_bit_cast(float, wx) * m : 0.f;
+                vd[i] = ok ? __builtin_bit_cast(float, wd) : 0.f;
+                bsum[k] += vd[i];
+            }
+            u32x4 hi, lo;
+            split8(vx, hi, lo);
+            s_x[0][c * DY_STRIDE + blk] = hi;
+            s_x[1][c * DY_STRIDE + blk] = lo;
+            split8(vd, hi, lo);
+            s_dy[0][c * DY_STRIDE + blk] = hi;
+            s_dy[1][c * DY_STRIDE + blk] = lo;
+        }
+        __syncthreads();
+        if (ch + 1 < c_end) issue(ch + 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int blk = 2 * ks + kg;
+            const int ai = (wm * 32 + l31) * DY_STRIDE + blk, bi = (wn * 32 + l31) * DY_STRIDE + blk;
+            const bf16x8 Ah = __builtin_bit_cast(bf16x8, s_dy[0][ai]), Al = __builtin_bit_cast(bf16x8, s_dy[1][ai]);
+            const bf16x8 Bh = __builtin_bit_cast(bf16x8, s_x[0][bi]), Bl = __builtin_bit_cast(bf16x8, s_x[1][bi]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc, 0, 0, 0);
+        }
+    }
+    float *out = a.part + ((size_t)slice * tiles + tile) * (64 * 64);
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+        const int co = wm * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kg;
+        out[co * 64 + wn * 32 + l31] = acc[rg];
+    }
+    if (a.dbpart && ci0 == 0) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float v = bsum[k];
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 4, 64);
+            if ((tid & 7) == 0) a.dbpart[(size_t)slice * a.cout + co0 + (tid >> 3) + 32 * k] = v;
+        }
+    }
+}
+
+static void wgrad1_geometry(int B, int cin, int cout, int HW, int W, Wgrad1Args &a) {
+    a.B = B; a.cin = cin; a.cout = cout; a.HW = HW; a.W = W;
+    a.cps = (HW + 63) / 64;
+    a.nchunk = B * a.cps;
+    const int tiles = (cin / 64) * (cout / 64);
+    int nslice = (512 + tiles - 1) / tiles;       // two workgroups per CU, at least four chunks each
+    nslice = std::max(1, std::min(nslice, (a.nchunk + 3) / 4));
+    a.nslice = nslice;
 }
 
 static void wgrad2_geometry(int B, int cin, int cout, int H, int W, Wgrad2Args &a) {
@@ -308,8 +424,8 @@ static void wgrad2_geometry(int B, int cin, int cout, int H, int W, Wgrad2Args &
     a.ncx = (W + 31) / 32; a.ncy = (H + 1) / 2;
     a.nchunk = B * a.ncy * a.ncx;
     const int tiles = (cin / 64) * (cout / 64);
-    // about three workgroups per CU across the chip, at least four chunks (256 pixels) per workgroup
-    int nslice = (768 + tiles - 1) / tiles;
+    // one eight-wave workgroup per CU across the chip, at least four chunks (256 pixels) per workgroup
+    int nslice = (256 + tiles - 1) / tiles;
     nslice = std::max(1, std::min(nslice, (a.nchunk + 3) / 4));
     a.nslice = nslice;
 }
@@ -339,9 +455,12 @@ extern "C" size_t gtts_conv3x3_wgrad_workspace_bytes(int B, int cin, int cout, i
     return ((size_t)a.nslice * (cin / 64) * (cout / 64) * (9 * 64 * 64) + (size_t)a.nslice * cout) * sizeof(float);
 }
 
-extern "C" int gtts_conv3x3_wgrad_tiled(const float *x, const float *mask, const float *dy, float *dw, float *db, void *workspace,
-                                        size_t workspace_bytes, int B, int cin, int cout, int H, int W, gtts_stream_t stream) {
+// x1 (nullable) / c0: the input is the channel concatenation of x [B,c0,H,W] and x1 [B,cin-c0,H,W] (c0 a multiple of 64)
+extern "C" int gtts_conv3x3_wgrad_tiled2(const float *x, const float *x1, int c0, const float *mask, const float *dy, float *dw, float *db,
+                                         void *workspace, size_t workspace_bytes, int B, int cin, int cout, int H, int W,
+                                         gtts_stream_t stream) {
     if (!x || !mask || !dy || !dw || !workspace) return wfail(GTTS_E_NULL, "gtts_conv3x3_wgrad_tiled: null argument");
+    if (x1 && (c0 <= 0 || c0 >= cin || c0 % 64)) return wfail(GTTS_E_SHAPE, "gtts_conv3x3_wgrad_tiled: c0 must be a multiple of 64 inside (0, cin) (got %d of %d)", c0, cin);
     if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || cin % 64 || cout % 64)
         return wfail(GTTS_E_SHAPE, "gtts_conv3x3_wgrad_tiled: cin and cout must be multiples of 64 (got %d, %d)", cin, cout);
     if ((size_t)std::max(cin, cout) * H * W >= ((size_t)1 << 30)) return wfail(GTTS_E_SHAPE, "gtts_conv3x3_wgrad_tiled: tensor too large");
@@ -350,10 +469,10 @@ extern "C" int gtts_conv3x3_wgrad_tiled(const float *x, const float *mask, const
     const size_t need = gtts_conv3x3_wgrad_workspace_bytes(B, cin, cout, H, W);
     if (workspace_bytes < need) return wfail(GTTS_E_WORKSPACE, "gtts_conv3x3_wgrad_tiled: workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     const int tiles = (cin / 64) * (cout / 64);
-    a.x = x; a.mask = mask; a.dy = dy; a.part = (float *)workspace;
+    a.x = x; a.x1 = x1; a.c0 = x1 ? c0 : cin; a.mask = mask; a.dy = dy; a.part = (float *)workspace;
     a.dbpart = db ? a.part + (size_t)a.nslice * tiles * (9 * 64 * 64) : nullptr;
     hipStream_t st = (hipStream_t)stream;
-    constexpr size_t smem = (size_t)(2 * 64 * DY_STRIDE + 2 * 64 * X_STRIDE) * 16;
+    constexpr size_t smem = (size_t)2 * (2 * 64 * DY_STRIDE + 2 * 64 * X_STRIDE) * 16;      // two buffers
     static std::atomic<int> attr_set[64];        // hipFuncSetAttribute is per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -361,11 +480,47 @@ extern "C" int gtts_conv3x3_wgrad_tiled(const float *x, const float *mask, const
         WCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wgrad2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set[dev].store(1, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL(conv3x3_wgrad2_kernel, dim3((unsigned)(tiles * a.nslice)), dim3(256), smem, st, a);
+    hipLaunchKernelGGL(conv3x3_wgrad2_kernel, dim3((unsigned)(tiles * a.nslice)), dim3(512), smem, st, a);
     WCHK(hipGetLastError());
     const size_t total = (size_t)tiles * (9 * 64 * 64) + (db ? (size_t)cout : 0);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, a.part, a.dbpart, dw, db, cin, cout,
-                       a.nslice);
+                       a.nslice, 9);
     WCHK(hipGetLastError());
     return GTTS_OK;
+}
+
+extern "C" size_t gtts_conv1x1_wgrad_workspace_bytes(int B, int cin, int cout, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || cin % 64 || cout % 64) return 0;
+    Wgrad1Args a;
+    wgrad1_geometry(B, cin, cout, H * W, W, a);
+    return ((size_t)a.nslice * (cin / 64) * (cout / 64) * (64 * 64) + (size_t)a.nslice * cout) * sizeof(float);
+}
+
+// dw [cout][cin], db [cout] (or null) of y = Conv2d_1x1(x * mask) + bias; mask [B][W] columns or null (no mask)
+extern "C" int gtts_conv1x1_wgrad(const float *x, const float *mask, const float *dy, float *dw, float *db, void *workspace,
+                                  size_t workspace_bytes, int B, int cin, int cout, int H, int W, gtts_stream_t stream) {
+    if (!x || !dy || !dw || !workspace) return wfail(GTTS_E_NULL, "gtts_conv1x1_wgrad: null argument");
+    if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || cin % 64 || cout % 64)
+        return wfail(GTTS_E_SHAPE, "gtts_conv1x1_wgrad: cin and cout must be multiples of 64 (got %d, %d)", cin, cout);
+    if ((size_t)B * std::max(cin, cout) * H * W >= ((size_t)1 << 29)) return wfail(GTTS_E_SHAPE, "gtts_conv1x1_wgrad: tensor too large");
+    Wgrad1Args a;
+    wgrad1_geometry(B, cin, cout, H * W, W, a);
+    const size_t need = gtts_conv1x1_wgrad_workspace_bytes(B, cin, cout, H, W);
+    if (workspace_bytes < need) return wfail(GTTS_E_WORKSPACE, "gtts_conv1x1_wgrad: workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    const int tiles = (cin / 64) * (cout / 64);
+    a.x = x; a.mask = mask; a.dy = dy; a.part = (float *)workspace;
+    a.dbpart = db ? a.part + (size_t)a.nslice * tiles * (64 * 64) : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3((unsigned)(tiles * a.nslice)), dim3(256), 0, st, a);
+    WCHK(hipGetLastError());
+    const size_t total = (size_t)tiles * (64 * 64) + (db ? (size_t)cout : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, a.part, a.dbpart, dw, db, cin, cout,
+                       a.nslice, 1);
+    WCHK(hipGetLastError());
+    return GTTS_OK;
+}
+
+extern "C" int gtts_conv3x3_wgrad_tiled(const float *x, const float *mask, const float *dy, float *dw, float *db, void *workspace,
+                                        size_t workspace_bytes, int B, int cin, int cout, int H, int W, gtts_stream_t stream) {
+    return gtts_conv3x3_wgrad_tiled2(x, nullptr, 0, mask, dy, dw, db, workspace, workspace_bytes, B, cin, cout, H, W, stream);
 }

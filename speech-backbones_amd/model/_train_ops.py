@@ -1,12 +1,17 @@
 """Autograd composition of the score U-Net -- TRAINING ONLY (the sampling path under torch.no_grad never comes here).
 
 Training (Diffusion.compute_loss -> loss_t -> estimator with autograd, Grad-TTS/model/diffusion.py:281-294) needs gradients
-w.r.t. the same nn.Parameters.  On HIP tensors the 3x3 Block convolutions -- 84 % of the network's FLOPs, forward and
-backward -- run on the hand-written kernels of csrc/train.hip (forward and data gradient on the inference MFMA kernel,
-weight gradient as an MFMA reduction over pixels) through `MaskedConv3x3`, every Block's GroupNorm + Mish + mask (forward and
-backward fused, csrc/train_norm.hip) through `GnMishMask`, and the loss head through `ScoreLoss`; attention, the 1x1 / resampling
-convolutions and the small MLPs are PyTorch-ROCm differentiable ops.
-On CPU tensors (tests) everything is stock torch.
+w.r.t. the same nn.Parameters.  On HIP tensors every tensor-sized op of the network runs on the hand-written kernels of
+csrc/train*.hip behind torch.autograd.Function wrappers:
+  MaskedConv3x3        Block's 3x3 convolution (forward / data gradient on the inference MFMA kernel, weight gradient as a
+                       wave-specialised MFMA reduction over pixels); the up path's torch.cat is read in place (two sources)
+  GnMishMask           GroupNorm + Mish + mask (+ ResnetBlock's time term), forward and backward fused
+  MaskedConv1x1        res_conv, to_qkv, to_out (forward / data gradient on the CONV_P1 kernel, MFMA weight gradient)
+  LinearAttentionCore  softmax over pixels, context, output (forward and backward)
+  RezeroResidual, MaskedResidualAdd, the plain residual add, FinalConv (64 -> 1 with both masks), ScoreLoss
+  DownConv / UpConv    Downsample / Upsample forward (and Downsample's data gradient) on the inference kernels; their weight
+                       gradients and Upsample's data gradient are the one part left on MIOpen (aten.convolution_backward)
+The [B, dim] time / speaker MLPs stay stock torch ops.  On CPU tensors (tests) everything is stock torch.
 """
 import math
 
@@ -17,14 +22,49 @@ from ._backend import backend
 
 
 class MaskedConv3x3(torch.autograd.Function):
-    """y = Conv2d_3x3(x * mask) + bias with all three gradients on the HIP kernels."""
+    """y = Conv2d_3x3(cat(x, x1) * mask) + bias with all three gradients on the HIP kernels (x1 None: one source)."""
+
+    @staticmethod
+    def forward(ctx, x, mask, weight, bias, x1=None):
+        be = backend()
+        cols = mask.reshape(mask.shape[0], mask.shape[-1])          # [B,1,1,W] -> [B,W]
+        ctx.save_for_backward(x, cols, weight, x1)
+        return be.conv3x3_masked(x, cols, weight, bias, x1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        be = backend()
+        x, cols, weight, x1 = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dx1 = dw = db = None
+        need1 = x1 is not None and ctx.needs_input_grad[4]
+        if ctx.needs_input_grad[0] or need1:
+            full = be.conv3x3_dgrad(dy, weight)
+            c0 = x.shape[1]
+            if x1 is None:
+                dx = be.add_masked(None, full, cols)
+            else:                                                   # mask and split in one pass each (contiguous results)
+                if ctx.needs_input_grad[0]:
+                    dx = be.add_masked(None, full, cols, channels=(0, c0))
+                if need1:
+                    dx1 = be.add_masked(None, full, cols, channels=(c0, full.shape[1]))
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:      # (one kernel produces both)
+            dw, db = be.conv3x3_wgrad(x, cols, dy, x1)
+        return dx, None, (dw if ctx.needs_input_grad[2] else None), (db if ctx.needs_input_grad[3] else None), dx1
+
+
+class MaskedConv1x1(torch.autograd.Function):
+    """y = Conv2d_1x1(x * mask) + bias (res_conv, to_qkv, to_out: diffusion.py:70,87-88; mask and bias optional) with all three
+    gradients on the HIP kernels.  A 1x1 convolution does not mix columns, so the mask of the data gradient is applied to dy
+    by the same kernel prologue."""
 
     @staticmethod
     def forward(ctx, x, mask, weight, bias):
         be = backend()
-        cols = mask.reshape(mask.shape[0], mask.shape[-1])          # [B,1,1,W] -> [B,W]
+        cols = None if mask is None else mask.reshape(mask.shape[0], mask.shape[-1])
         ctx.save_for_backward(x, cols, weight)
-        return be.conv3x3_masked(x, cols, weight, bias)
+        ctx.has_bias = bias is not None
+        return be.conv1x1_masked(x, cols, weight, bias)
 
     @staticmethod
     def backward(ctx, dy):
@@ -33,29 +73,127 @@ class MaskedConv3x3(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = be.conv3x3_dgrad(dy, weight) * cols[:, None, None, :]
-        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:      # (one kernel produces both)
-            dw, db = be.conv3x3_wgrad(x, cols, dy)
-        return dx, None, (dw if ctx.needs_input_grad[2] else None), (db if ctx.needs_input_grad[3] else None)
+            dx = be.conv1x1_dgrad(dy, weight, cols)
+        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+            dw, db = be.conv1x1_wgrad(x, cols, dy, want_bias=ctx.has_bias)
+        return dx, None, (dw if ctx.needs_input_grad[2] else None), (db if ctx.has_bias and ctx.needs_input_grad[3] else None)
+
+
+class LinearAttentionCore(torch.autograd.Function):
+    """softmax over pixels of k, context = k~ v^T, out = context^T q (LinearAttention.forward between its two 1x1 convolutions,
+    diffusion.py:90-100) on to_qkv's output [B, 384, H, W]; forward and backward on csrc/train_attn.hip."""
+
+    @staticmethod
+    def forward(ctx, qkv):
+        out, c, stat = backend().attn_train_forward(qkv)
+        ctx.save_for_backward(qkv, c, stat)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, c, stat = ctx.saved_tensors
+        return backend().attn_train_backward(qkv, dout.contiguous(), c, stat)
+
+
+class RezeroResidual(torch.autograd.Function):
+    """f * g + x (Residual(Rezero(fn)), diffusion.py:40-46,103-108) with d f = dy * g, d g = sum(dy * f), d x = dy."""
+
+    @staticmethod
+    def forward(ctx, f, g, x):
+        ctx.save_for_backward(f, g)
+        return backend().rezero_forward(f, g, x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        f, g = ctx.saved_tensors
+        dy = dy.contiguous()
+        df, dg = backend().rezero_backward(dy, f, g)
+        return df, dg, dy
 
 
 class GnMishMask(torch.autograd.Function):
-    """Mish(GroupNorm(y)) * mask (Block.forward, diffusion.py:53-58) with forward and backward on the HIP kernels."""
+    """Mish(GroupNorm(y)) * mask (Block.forward, diffusion.py:53-58) [+ tb[:, :, None, None]: ResnetBlock's time term,
+    diffusion.py:75-76] with forward and backward on the HIP kernels."""
 
     @staticmethod
-    def forward(ctx, y, mask, gamma, beta, groups, eps):
+    def forward(ctx, y, mask, gamma, beta, groups, eps, tb=None):
         be = backend()
         cols = mask.reshape(mask.shape[0], mask.shape[-1])          # [B,1,1,W] -> [B,W]
-        out, stats = be.gn_mish_forward(y, gamma, beta, cols, groups, eps)
+        out, stats = be.gn_mish_forward(y, gamma, beta, cols, groups, eps, tb)
         ctx.save_for_backward(y, cols, gamma, beta, stats)
         ctx.groups = groups
+        ctx.has_tb = tb is not None
         return out
 
     @staticmethod
     def backward(ctx, dout):
         y, cols, gamma, beta, stats = ctx.saved_tensors
-        dy, dg, db = backend().gn_mish_backward(dout.contiguous(), y, gamma, beta, cols, stats, ctx.groups)
-        return dy, None, dg, db, None, None
+        r = backend().gn_mish_backward(dout.contiguous(), y, gamma, beta, cols, stats, ctx.groups, want_dtb=ctx.has_tb)
+        return r[0], None, r[1], r[2], None, None, (r[3] if ctx.has_tb else None)
+
+
+class MaskedResidualAdd(torch.autograd.Function):
+    """h + v * mask (ResnetBlock with an identity res_conv, diffusion.py:77-78; mask None: h + v)."""
+
+    @staticmethod
+    def forward(ctx, h, v, mask):
+        cols = None if mask is None else mask.reshape(mask.shape[0], mask.shape[-1])
+        ctx.save_for_backward(cols)
+        return backend().add_masked(h, v, cols)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (cols,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        dv = dout if cols is None else (backend().add_masked(None, dout, cols) if ctx.needs_input_grad[1] else None)
+        return dout, dv, None
+
+
+class FinalConv(torch.autograd.Function):
+    """(final_conv(x * mask)) * mask for the 64 -> 1 convolution (diffusion.py:175-176)."""
+
+    @staticmethod
+    def forward(ctx, x, mask, weight, bias):
+        cols = mask.reshape(mask.shape[0], mask.shape[-1])
+        ctx.save_for_backward(x, cols, weight)
+        return backend().final_conv_forward(x, weight, bias, cols)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, cols, weight = ctx.saved_tensors
+        dx, dw, db = backend().final_conv_backward(x, weight, cols, dout.contiguous())
+        return dx, None, dw, db
+
+
+class ResampleConv(torch.autograd.Function):
+    """Downsample / Upsample of x * mask (diffusion.py:19-34,158,171): forward on the inference kernels; Downsample's data
+    gradient is an Upsample call with the zero-padded kernel; the weight gradients and Upsample's data gradient are MIOpen's."""
+
+    @staticmethod
+    def forward(ctx, x, mask, weight, bias, up):
+        cols = mask.reshape(mask.shape[0], mask.shape[-1])
+        ctx.save_for_backward(x, cols, weight)
+        ctx.up = bool(up)
+        ctx.bias_n = int(bias.shape[0])
+        return backend().conv_resample(x, cols, weight, bias, up)
+
+    @staticmethod
+    def backward(ctx, dy):
+        be = backend()
+        x, cols, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        xm = be.add_masked(None, x, cols)
+        need_dx = ctx.needs_input_grad[0]
+        aten_dx = need_dx and ctx.up
+        gi, gw, gb = torch.ops.aten.convolution_backward(dy, xm, weight, [ctx.bias_n], [2, 2], [1, 1], [1, 1], ctx.up, [0, 0], 1,
+                                                         [aten_dx, True, True])
+        dx = None
+        if need_dx:
+            if not ctx.up:
+                ones = be._const(dy.device, "ones", int(dy.shape[0]), int(dy.shape[3]))
+                gi = be.conv_resample(dy, ones, weight, None, True, dgrad_of_down=True)
+            dx = be.add_masked(None, gi, cols)
+        return dx, None, gw, gb, None
 
 
 class ScoreLoss(torch.autograd.Function):
@@ -81,43 +219,86 @@ def _hip_conv_ok(v, conv):
             backend().conv3x3_supported(conv.in_channels, conv.out_channels))
 
 
+def _conv1x1(v, m, conv):
+    """conv(v * m) for a 1x1 nn.Conv2d (m None: no mask)."""
+    if (not FORCE_TORCH and v.is_cuda and v.dtype == torch.float32 and conv.kernel_size == (1, 1) and
+            backend().conv1x1_supported(conv.in_channels, conv.out_channels, need_dgrad=v.requires_grad)):
+        return MaskedConv1x1.apply(v.contiguous(), m, conv.weight, conv.bias)
+    return F.conv2d(v if m is None else v * m, conv.weight, conv.bias)
+
+
 def _mish(v):
     return v * torch.tanh(F.softplus(v))
 
 
-def _conv_gn_mish(blk, v, m):
+def _hip(v):
+    return not FORCE_TORCH and v.is_cuda and v.dtype == torch.float32
+
+
+def _conv_gn_mish(blk, v, m, tb=None, v1=None):
+    """Block.forward [+ the time term tb[:, :, None, None]] on v (or on the concatenation cat(v, v1), read in place)."""
     conv, norm = blk.block[0], blk.block[1]
+    if v1 is not None and not (_hip_conv_ok(v, conv) and v.shape[1] % 64 == 0):
+        v, v1 = torch.cat((v, v1), dim=1), None
     if _hip_conv_ok(v, conv):
-        y = MaskedConv3x3.apply(v.contiguous(), m, conv.weight, conv.bias)
+        y = MaskedConv3x3.apply(v.contiguous(), m, conv.weight, conv.bias, None if v1 is None else v1.contiguous())
     else:
         y = F.conv2d(v * m, conv.weight, conv.bias, padding=1)
-    if y.is_cuda and y.dtype == torch.float32 and not FORCE_TORCH and y.dim() == 4 and y.shape[1] % norm.num_groups == 0:
-        return GnMishMask.apply(y.contiguous(), m, norm.weight, norm.bias, norm.num_groups, norm.eps)
+    if _hip(y) and y.dim() == 4 and y.shape[1] % norm.num_groups == 0:
+        return GnMishMask.apply(y.contiguous(), m, norm.weight, norm.bias, norm.num_groups, norm.eps,
+                                None if tb is None else tb.contiguous())
     y = F.group_norm(y, norm.num_groups, norm.weight, norm.bias, norm.eps)
-    return _mish(y) * m
+    y = _mish(y) * m
+    return y if tb is None else y + tb[:, :, None, None]
 
 
-def resnet(rb, v, m, temb):
+def resnet(rb, v, m, temb, v1=None):
+    """ResnetBlock.forward (diffusion.py:73-78) on v, or on cat(v, v1) without materialising it."""
     lin = rb.mlp[1]
-    h = _conv_gn_mish(rb.block1, v, m)
-    h = h + F.linear(_mish(temb), lin.weight, lin.bias)[:, :, None, None]
+    tb = F.linear(_mish(temb), lin.weight, lin.bias)
+    h = _conv_gn_mish(rb.block1, v, m, tb=tb, v1=v1)
     h = _conv_gn_mish(rb.block2, h, m)
     if isinstance(rb.res_conv, torch.nn.Conv2d):
-        return h + F.conv2d(v * m, rb.res_conv.weight, rb.res_conv.bias)
-    return h + v * m
+        rc = rb.res_conv
+        if v1 is None:
+            r = _conv1x1(v, m, rc)
+        elif _hip(v) and backend().conv1x1_supported(v.shape[1], rc.out_channels) and backend().conv1x1_supported(v1.shape[1], rc.out_channels):
+            # a 1x1 convolution of a concatenation is the sum of the convolutions of its parts with the weight's column blocks
+            c0 = v.shape[1]
+            r = MaskedConv1x1.apply(v.contiguous(), m, rc.weight[:, :c0].contiguous(), rc.bias)
+            r = MaskedResidualAdd.apply(r, MaskedConv1x1.apply(v1.contiguous(), m, rc.weight[:, c0:].contiguous(), None), None)
+        else:
+            r = F.conv2d(torch.cat((v, v1), dim=1) * m, rc.weight, rc.bias)
+        return MaskedResidualAdd.apply(h, r.contiguous(), None) if _hip(h) else h + r
+    if v1 is not None:
+        v = torch.cat((v, v1), dim=1)
+    return MaskedResidualAdd.apply(h, v.contiguous(), m) if _hip(h) else h + v * m
+
+
+def _resample(v, m, conv, up):
+    if _hip(v) and backend().resample_supported(v.shape[1], conv.out_channels, v.shape[2], v.shape[3], up):
+        return ResampleConv.apply(v.contiguous(), m, conv.weight, conv.bias, up)
+    return conv(v * m)
 
 
 def attention(res, v):
     rez = res.fn
     att = rez.fn
     b, c, hh, ww = v.shape
-    qkv = F.conv2d(v, att.to_qkv.weight).view(b, 3, att.heads, -1, hh * ww)
-    q, k, val = qkv.unbind(1)
-    k = torch.softmax(k, dim=-1)
-    ctx = torch.matmul(k, val.transpose(-1, -2))            # [b, heads, d, e]
-    out = torch.matmul(ctx.transpose(-1, -2), q)            # [b, heads, e, n]
-    out = out.reshape(b, -1, hh, ww)
-    y = F.conv2d(out, att.to_out.weight, att.to_out.bias)
+    qkv = _conv1x1(v, None, att.to_qkv)
+    hip = (not FORCE_TORCH and v.is_cuda and v.dtype == torch.float32 and att.heads == 4 and qkv.shape[1] == 384 and
+           v.numel() % 4 == 0)
+    if hip:
+        out = LinearAttentionCore.apply(qkv.contiguous())
+    else:
+        q, k, val = qkv.view(b, 3, att.heads, -1, hh * ww).unbind(1)
+        k = torch.softmax(k, dim=-1)
+        ctx = torch.matmul(k, val.transpose(-1, -2))            # [b, heads, d, e]
+        out = torch.matmul(ctx.transpose(-1, -2), q)            # [b, heads, e, n]
+        out = out.reshape(b, -1, hh, ww)
+    y = _conv1x1(out, None, att.to_out)
+    if hip:
+        return RezeroResidual.apply(y.contiguous(), rez.g, v.contiguous())
     return y * rez.g + v
 
 
@@ -145,17 +326,19 @@ def estimator(est, x, mask, mu, t, spk=None):
         v = attention(att, resnet(r2, resnet(r1, v, m, temb), m, temb))
         skips.append(v)
         if not isinstance(down, torch.nn.Identity):
-            v = down.conv(v * m)
-        pyramid.append(m[..., ::2])
+            v = _resample(v, m, down.conv, False)
+        pyramid.append(m[..., ::2].contiguous())        # (contiguous: every op below takes its [B, W] view without a copy)
     pyramid.pop()
     m = pyramid[-1]
     v = resnet(est.mid_block2, attention(est.mid_attn, resnet(est.mid_block1, v, m, temb)), m, temb)
     for r1, r2, att, up in est.ups:
         m = pyramid.pop()
-        v = torch.cat((v, skips.pop()), dim=1)
-        v = attention(att, resnet(r2, resnet(r1, v, m, temb), m, temb))
-        v = up.conv(v * m)
+        v = attention(att, resnet(r2, resnet(r1, v, m, temb, v1=skips.pop()), m, temb))       # (torch.cat read in place)
+        v = _resample(v, m, up.conv, True)
     m = mask[:, None]
     v = _conv_gn_mish(est.final_block, v, m)
-    out = F.conv2d(v * m, est.final_conv.weight, est.final_conv.bias)
+    fc = est.final_conv
+    if _hip(v) and fc.out_channels == 1:
+        return FinalConv.apply(v.contiguous(), m, fc.weight, fc.bias).squeeze(1)
+    out = F.conv2d(v * m, fc.weight, fc.bias)
     return (out * m).squeeze(1)

@@ -55,6 +55,133 @@ def test_conv3x3_forward_dgrad_wgrad(S, dev, B, cin, cout, H, W):
     assert float((xg.grad.cpu() * (1 - mask)).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,cin,cout,H,W,masked,bias", [(2, 64, 128, 80, 44, True, True), (3, 128, 384, 40, 17, False, False),
+                                                        (1, 256, 384, 20, 43, False, False), (2, 128, 256, 10, 13, False, True),
+                                                        (2, 512, 128, 20, 16, True, True), (2, 128, 64, 7, 33, True, True)])
+def test_conv1x1_forward_dgrad_wgrad(S, dev, B, cin, cout, H, W, masked, bias):
+    """y = conv1x1(x * mask) + b (res_conv: masked, biased; to_qkv: neither; to_out: biased) and its gradients against torch
+    autograd (CPU fp32); plane sizes that are not multiples of the 64-pixel chunk, ragged masks."""
+    T = importlib.import_module("speech-backbones_amd.model._train_ops")
+    g = torch.Generator().manual_seed(cin + W)
+    x = torch.randn(B, cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).requires_grad_(True)
+    b = torch.randn(cout, generator=g).requires_grad_(True) if bias else None
+    lens = torch.tensor([W] + [max(1, W - 5 * (k + 1)) for k in range(B - 1)])
+    mask = O.sequence_mask(lens, W).float()[:, None, None, :] if masked else None
+    dy = torch.randn(B, cout, H, W, generator=g)
+    y_ref = F.conv2d(x * mask if masked else x, w, b)
+    y_ref.backward(dy)
+    xg, wg = (t.detach().clone().to(dev).requires_grad_(True) for t in (x, w))
+    bg = b.detach().clone().to(dev).requires_grad_(True) if bias else None
+    y = T.MaskedConv1x1.apply(xg, mask.to(dev) if masked else None, wg, bg)
+    y.backward(dy.to(dev))
+    assert relerr(y.detach().cpu(), y_ref.detach()) <= REL
+    assert relerr(xg.grad.cpu(), x.grad) <= REL
+    assert relerr(wg.grad.cpu(), w.grad) <= REL
+    if bias:
+        assert relerr(bg.grad.cpu(), b.grad) <= REL
+    if masked:
+        assert float((xg.grad.cpu() * (1 - mask)).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 80, 44), (3, 128, 40, 43), (1, 256, 20, 13), (4, 64, 7, 150)])
+def test_linear_attention_core_and_rezero(S, dev, B, C, H, W):
+    """LinearAttention (to_qkv -> softmax over pixels -> context -> out -> to_out) under Residual(Rezero(.)) -- diffusion.py:82-108
+    -- forward and every gradient against torch autograd on the CPU: the 1x1 convolutions, the attention core (sliced online
+    softmax: H*W from 150 to 3520 pixels, i.e. 1 to 7 slices) and the Rezero residual on the HIP kernels."""
+    T = importlib.import_module("speech-backbones_amd.model._train_ops")
+    D = importlib.import_module("speech-backbones_amd.model.diffusion")
+    torch.manual_seed(C + W)
+    res = D.Residual(D.Rezero(D.LinearAttention(C)))
+    with torch.no_grad():
+        res.fn.g.fill_(0.7)
+    x = (1.5 * torch.randn(B, C, H, W)).requires_grad_(True)
+    dy = torch.randn(B, C, H, W)
+    y_ref = T.attention(res, x)                   # CPU tensors: the stock-op composition (pinned to the reference in test_model_cpu)
+    y_ref.backward(dy)
+    ref_grads = {n: p.grad.clone() for n, p in res.named_parameters()}
+    gres = copy.deepcopy(res).to(dev)
+    gres.zero_grad(set_to_none=True)
+    xg = x.detach().clone().to(dev).requires_grad_(True)
+    y = T.attention(gres, xg)
+    y.backward(dy.to(dev))
+    assert relerr(y.detach().cpu(), y_ref.detach()) <= REL
+    assert relerr(xg.grad.cpu(), x.grad) <= REL
+    for n, p in gres.named_parameters():
+        if n == "fn.g":
+            # Rezero's scalar gradient sum(dy * f) is a cancelling sum of ~1e5 random-sign terms: its error is measured against
+            # the Cauchy-Schwarz scale |dy| |f| of the sum, not against the cancelled result
+            f = (y_ref.detach() - x.detach()) / 0.7
+            assert abs(float(p.grad.cpu()) - float(ref_grads[n])) <= 1e-5 * float(dy.norm() * f.norm()), n
+            continue
+        assert relerr(p.grad.cpu(), ref_grads[n]) <= 2 * REL, n
+
+
+@pytest.mark.parametrize("up,B,cin,cout,H,W", [(False, 2, 64, 64, 80, 44), (False, 3, 128, 128, 40, 86), (True, 2, 128, 128, 20, 43),
+                                               (True, 3, 64, 64, 40, 22)])
+def test_resample_conv_forward_backward(S, dev, up, B, cin, cout, H, W):
+    """Downsample / Upsample of x * mask (diffusion.py:19-34) and all three gradients against torch autograd on the CPU."""
+    T = importlib.import_module("speech-backbones_amd.model._train_ops")
+    g = torch.Generator().manual_seed(cin + W)
+    x = torch.randn(B, cin, H, W, generator=g, requires_grad=True)
+    conv = torch.nn.ConvTranspose2d(cin, cout, 4, 2, 1) if up else torch.nn.Conv2d(cin, cout, 3, 2, 1)
+    lens = torch.tensor([W] + [max(1, W - 5 * (k + 1)) for k in range(B - 1)])
+    mask = O.sequence_mask(lens, W).float()[:, None, None, :]
+    y_ref = conv(x * mask)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    gconv = copy.deepcopy(conv).to(dev)
+    gconv.zero_grad(set_to_none=True)
+    xg = x.detach().clone().to(dev).requires_grad_(True)
+    y = T.ResampleConv.apply(xg, mask.to(dev), gconv.weight, gconv.bias, up)
+    y.backward(dy.to(dev))
+    assert relerr(y.detach().cpu(), y_ref.detach()) <= REL
+    assert relerr(xg.grad.cpu(), x.grad) <= REL
+    assert relerr(gconv.weight.grad.cpu(), conv.weight.grad) <= REL
+    assert relerr(gconv.bias.grad.cpu(), conv.bias.grad) <= REL
+    assert float((xg.grad.cpu() * (1 - mask)).abs().max()) == 0.0
+
+
+def test_two_source_conv_time_bias_residual_and_final_conv(S, dev):
+    """An up-path ResnetBlock on (v, skip) without the torch.cat (two-source 3x3 forward / weight gradient, split data gradient,
+    two-part res_conv), the time term inside GnMishMask, the residual adds and the final 64 -> 1 convolution: output and every
+    gradient against the same module on the CPU (stock ops, concatenated input)."""
+    T = importlib.import_module("speech-backbones_amd.model._train_ops")
+    D = importlib.import_module("speech-backbones_amd.model.diffusion")
+    torch.manual_seed(5)
+    B, H, W = 3, 20, 43
+    rb = D.ResnetBlock(256, 64, time_emb_dim=64)
+    rb2 = D.ResnetBlock(64, 64, time_emb_dim=64)
+    fc = torch.nn.Conv2d(64, 1, 1)
+    v = torch.randn(B, 128, H, W).requires_grad_(True)
+    skip = torch.randn(B, 128, H, W).requires_grad_(True)
+    temb = torch.randn(B, 64).requires_grad_(True)
+    lens = torch.tensor([W, W - 9, 11])
+    mask = O.sequence_mask(lens, W).float()[:, None, None, :]
+
+    def run(rb_, rb2_, fc_, v_, s_, t_, m_):
+        h = T.resnet(rb2_, T.resnet(rb_, v_, m_, t_, v1=s_), m_, t_)
+        if h.is_cuda:
+            return T.FinalConv.apply(h, m_, fc_.weight, fc_.bias)
+        return F.conv2d(h * m_, fc_.weight, fc_.bias) * m_
+    out_ref = run(rb, rb2, fc, v, skip, temb, mask)
+    dy = torch.randn(out_ref.shape)
+    out_ref.backward(dy)
+    mods = [copy.deepcopy(m_).to(dev) for m_ in (rb, rb2, fc)]
+    for m_ in mods:
+        m_.zero_grad(set_to_none=True)
+    vg, sg, tg = (t_.detach().clone().to(dev).requires_grad_(True) for t_ in (v, skip, temb))
+    out = run(mods[0], mods[1], mods[2], vg, sg, tg, mask.to(dev))
+    out.backward(dy.to(dev))
+    assert relerr(out.detach().cpu(), out_ref.detach()) <= REL
+    for a, b, n in ((vg, v, "v"), (sg, skip, "skip"), (tg, temb, "temb")):
+        assert relerr(a.grad.cpu(), b.grad) <= 2 * REL, n
+    for gm, cm in zip(mods, (rb, rb2, fc)):
+        cg = dict(cm.named_parameters())
+        for n, p in gm.named_parameters():
+            assert relerr(p.grad.cpu(), cg[n].grad) <= 2 * REL, n
+
+
 @pytest.mark.parametrize("B,C,H,W", [(2, 64, 80, 44), (3, 128, 40, 17), (1, 256, 20, 13), (2, 16, 5, 7)])
 def test_gn_mish_forward_backward(S, dev, B, C, H, W):
     """Mish(GroupNorm_8(y)) * mask (Block.forward, diffusion.py:53-58) and all three gradients (dy, dgamma, dbeta) against torch
