@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GTTS_ABI_VERSION 2
+#define GTTS_ABI_VERSION 3
 
 enum {
     GTTS_OK = 0,
@@ -295,6 +295,67 @@ size_t gtts_gn_mish_scratch_bytes(int B, int C);
 int gtts_gn_mish_backward(const float *dout, const float *y, const float *gamma, const float *beta, const float *mask,
                           const float *stats, float *dy, float *dgamma, float *dbeta, void *scratch, int B, int C, int H, int W,
                           int groups, gtts_stream_t stream);
+
+/* ---- training hot path, the rest of the score network (ABI 3; Grad-TTS/model/diffusion.py:19-108,140-176) ----------------
+ * Every tensor-sized op of Diffusion.compute_loss's forward and backward except Upsample's gradients (MIOpen). */
+/* Block's convolution on a channel concatenation read in place (torch.cat of the up path, diffusion.py:166): x [B,c0,H,W],
+ * x1 [B,cin-c0,H,W] (nullptr: one source, c0 ignored); c0 a multiple of 16 (forward) / 64 (weight gradient). */
+int gtts_conv3x3_masked2(const float *x, const float *x1, int c0, const float *mask, const void *packed, const float *bias, float *y,
+                         int B, int cin, int cout, int H, int W, gtts_stream_t stream);
+int gtts_conv3x3_wgrad_tiled2(const float *x, const float *x1, int c0, const float *mask, const float *dy, float *dw, float *db,
+                              void *workspace, size_t workspace_bytes, int B, int cin, int cout, int H, int W, gtts_stream_t stream);
+/* 1x1 convolutions (res_conv, to_qkv, to_out: diffusion.py:70,87-88): y = Conv2d_1x1(x * mask) + bias; the data gradient is the
+ * same call on dy with weights packed transposed = 1 (the mask then applies to dy: columns do not mix); weight gradient
+ * dw [cout][cin], db [cout] (nullable); mask [B,W] (nullable in the weight gradient).  cin, cout multiples of 64. */
+size_t gtts_conv1x1_packed_bytes(int cin, int cout);
+int gtts_conv1x1_pack(const float *w, void *packed, int cin, int cout, int transposed, gtts_stream_t stream);
+int gtts_conv1x1_masked(const float *x, const float *mask, const void *packed, const float *bias, float *y, int B, int cin,
+                        int cout, int H, int W, gtts_stream_t stream);
+size_t gtts_conv1x1_wgrad_workspace_bytes(int B, int cin, int cout, int H, int W);
+int gtts_conv1x1_wgrad(const float *x, const float *mask, const float *dy, float *dw, float *db, void *workspace,
+                       size_t workspace_bytes, int B, int cin, int cout, int H, int W, gtts_stream_t stream);
+/* First-layer weight gradient (stacked (mu, x[, spk]) input: cin 2 or 3; ksize 3 or 1): dw [cout][cin][k][k], db [cout]. */
+size_t gtts_conv_wgrad_small_scratch_floats(int B, int cin, int cout, int ksize);
+int gtts_conv_wgrad_small(const float *x, const float *mask, const float *dy, float *dw, float *db, float *scratch, int B, int cin,
+                          int cout, int H, int W, int ksize, gtts_stream_t stream);
+/* Downsample (up = 0: Conv2d 3x3 stride 2 pad 1, w [cout][cin][3][3]) / Upsample (up = 1: ConvTranspose2d 4x4 stride 2 pad 1,
+ * w [cin][cout][4][4]) of x * mask (diffusion.py:19-34); x [B,cin,H,W], mask [B,W], y [B,cout,H/2,W/2] or [B,cout,2H,2W].
+ * Downsample's data gradient is the up = 1 call on dy with its forward weight zero-padded to 4x4. */
+size_t gtts_conv_resample_packed_bytes(int cin, int cout, int up);
+int gtts_conv_resample_pack(const float *w, void *packed, int cin, int cout, int up, gtts_stream_t stream);
+int gtts_conv_resample(const float *x, const float *mask, const void *packed, const float *bias, float *y, int B, int cin, int cout,
+                       int H, int W, int up, gtts_stream_t stream);
+int gtts_zero_insert2(const float *in, float *out, int B, int C, int h, int w, gtts_stream_t stream);
+/* GroupNorm + Mish + mask with ResnetBlock's time term: out = Mish(GroupNorm(y)) * mask + tb[b,c] (tb, dtb [B][C], nullable). */
+int gtts_gn_mish_forward_tb(const float *y, const float *gamma, const float *beta, const float *mask, const float *tb, float *out,
+                            float *stats, int B, int C, int H, int W, int groups, float eps, gtts_stream_t stream);
+int gtts_gn_mish_backward_tb(const float *dout, const float *y, const float *gamma, const float *beta, const float *mask,
+                             const float *stats, float *dy, float *dgamma, float *dbeta, float *dtb, void *scratch, int B, int C,
+                             int H, int W, int groups, gtts_stream_t stream);
+/* LinearAttention between its two 1x1 convolutions (diffusion.py:90-100): qkv [B][384][N] -> out [B][128][N]; ctx [B][4][32][32]
+ * and stat [B][4][32][2] (softmax row maximum, reciprocal sum) are kept for the backward call, which writes dqkv [B][384][N];
+ * dctx [B][4][32][32], rdot [B][4][32]: outputs used as scratch; scratch: gtts_attn_train_scratch_floats(B, N) floats. */
+size_t gtts_attn_train_scratch_floats(int B, int N);
+int gtts_attn_train_forward(const float *qkv, float *out, float *ctx, float *stat, float *scratch, int B, int N, gtts_stream_t stream);
+int gtts_attn_train_backward(const float *qkv, const float *dout, const float *ctx, const float *stat, float *dqkv, float *dctx,
+                             float *rdot, float *scratch, int B, int N, gtts_stream_t stream);
+/* Residual(Rezero(f)): y = f * g + x, g one device scalar (diffusion.py:40-46,103-108); backward df = dy * g, dg = sum(dy * f);
+ * n floats, a multiple of 4; scratch: gtts_rezero_scratch_bytes(n) bytes. */
+int gtts_rezero_forward(const float *f, const float *x, const float *g, float *y, size_t n, gtts_stream_t stream);
+size_t gtts_rezero_scratch_bytes(size_t n);
+int gtts_rezero_backward(const float *dy, const float *f, const float *g, float *df, float *dg, void *scratch, size_t n,
+                         gtts_stream_t stream);
+/* out = a + b * mask over [B,C,H,W], mask [B,W] (a nullable: b * mask; mask nullable: a + b); b_cstride > 0: b is a C-channel
+ * slice of a contiguous tensor with b_cstride channels (the split of a concatenation's gradient). */
+int gtts_add_masked(const float *a, const float *b, const float *mask, float *out, int B, int C, int H, int W, int b_cstride,
+                    gtts_stream_t stream);
+/* final_conv (C -> 1) with both masks (diffusion.py:175-176): out [B,1,H,W] = (sum_c w[c] x[b,c] m + bias) m and its gradients
+ * dx [B,C,H,W], dw [C], db [1]; scratch: gtts_final_conv_scratch_floats(B, C, H, W) floats. */
+int gtts_final_conv_forward(const float *x, const float *w, const float *bias, const float *mask, float *out, int B, int C, int H,
+                            int W, gtts_stream_t stream);
+size_t gtts_final_conv_scratch_floats(int B, int C, int H, int W);
+int gtts_final_conv_backward(const float *x, const float *w, const float *mask, const float *dout, float *dx, float *dw, float *db,
+                             float *scratch, int B, int C, int H, int W, gtts_stream_t stream);
 
 /* ---- debugging / tests: named intermediates of the last estimator call (keep_intermediates plans) ----- */
 int gtts_plan_num_tensors(const gtts_plan *plan);

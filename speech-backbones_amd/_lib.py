@@ -109,6 +109,10 @@ def lib():
         L.gtts_gn_mish_forward_tb.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, f, vp]
         L.gtts_gn_mish_backward_tb.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, vp]
         L.gtts_add_masked.argtypes = [vp, vp, vp, vp, i, i, i, i, i, vp]
+        L.gtts_conv_wgrad_small_scratch_floats.argtypes = [i, i, i, i]
+        L.gtts_conv_wgrad_small_scratch_floats.restype = sz
+        L.gtts_conv_wgrad_small.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
+        L.gtts_zero_insert2.argtypes = [vp, vp, i, i, i, i, vp]
         L.gtts_final_conv_forward.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp]
         L.gtts_final_conv_scratch_floats.argtypes = [i, i, i, i]
         L.gtts_final_conv_scratch_floats.restype = sz
@@ -175,7 +179,7 @@ def lib():
                                         ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         L.gtts_profile_enable.argtypes = [vp, i]
         L.gtts_profile_collect.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]
-        if L.gtts_abi_version() != 2:
+        if L.gtts_abi_version() != 3:
             raise RuntimeError("libgradtts_gfx950.so ABI version mismatch")
         _lib = L
         return _lib
@@ -188,6 +192,25 @@ def _check(rc, what):
 
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _NoSwitch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def _on(device):
+    """Context that makes `device` current for the launches inside -- free when it already is (the training wrappers run
+    ~600 launches per step; torch.cuda.device() costs more host time than the launch it guards)."""
+    if device.index is None or device.index == torch.cuda.current_device():
+        return _NO_SWITCH
+    return torch.cuda.device(device)
 
 
 def _ptr(t):
@@ -828,10 +851,13 @@ def mas_maximum_path(value, mask):
 
 
 # ---- training hot path (csrc/train.hip): raw kernels; the autograd wiring lives in model/_train_ops.py
-def conv3x3_supported(cin, cout):
-    """Channel counts the training conv kernels take (forward / data gradient / weight gradient)."""
+def conv3x3_supported(cin, cout, need_dgrad=True):
+    """Channel counts the training conv kernels take (forward / data gradient / weight gradient).  The first layer (the stacked
+    2- or 3-plane input, no data gradient wanted) has its own weight-gradient kernel."""
     def tiles(c):
         return c == 64 or (c > 64 and c % 128 == 0)
+    if cin in (2, 3) and not need_dgrad:
+        return tiles(cout)
     return cin % 32 == 0 and cout % 32 == 0 and tiles(cin) and tiles(cout)
 
 
@@ -887,7 +913,7 @@ def _conv3x3_run(x, mask_cols, weight, bias, transposed, x1=None):
     cout = weight.shape[1] if transposed else weight.shape[0]
     L = lib()
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         packed = _packed_conv3x3(weight, cin, cout, transposed)
         _check(L.gtts_conv3x3_masked2(_ptr(x), _ptr(x1), c0, _ptr(mask_cols), _ptr(packed), _ptr(bias), _ptr(y), B, cin, cout, H, W,
                                       _stream()), "gtts_conv3x3_masked")
@@ -916,8 +942,10 @@ def conv3x3_wgrad(x, mask_cols, dy, x1=None):
     cout = dy.shape[1]
     dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
     db = torch.empty((cout,), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
-        if cin % 64 == 0 and cout % 64 == 0:       # LDS-tiled deterministic reduction (train_wgrad.hip)
+    with _on(x.device):
+        if cin in (2, 3) and x1 is None:
+            _wgrad_small(x, mask_cols, dy, dw, db, 3)
+        elif cin % 64 == 0 and cout % 64 == 0:       # LDS-tiled deterministic reduction (train_wgrad.hip)
             nws = int(lib().gtts_conv3x3_wgrad_workspace_bytes(B, cin, cout, H, W))
             ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
             _check(lib().gtts_conv3x3_wgrad_tiled2(_ptr(x), _ptr(x1), c0, _ptr(mask_cols), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), nws,
@@ -935,6 +963,8 @@ def conv1x1_supported(cin, cout, need_dgrad=True):
     kernel's output tiles; the weight gradient whole 64 x 64 tiles."""
     def tiles(c):
         return c == 64 or (c > 64 and c % 128 == 0)
+    if cin in (2, 3) and not need_dgrad:          # first layer: own weight-gradient kernel
+        return tiles(cout)
     return tiles(cout) and cin % 64 == 0 and (tiles(cin) or not need_dgrad)
 
 
@@ -946,7 +976,7 @@ def _conv1x1_run(x, mask_cols, weight, bias, transposed):
     B, cin, H, W = x.shape
     cout = weight.shape[1] if transposed else weight.shape[0]
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         packed = _packed_conv1x1(weight, cin, cout, transposed)
         _check(lib().gtts_conv1x1_masked(_ptr(x), _ptr(mask_cols), _ptr(packed), _ptr(bias), _ptr(y), B, cin, cout, H, W, _stream()),
                "gtts_conv1x1_masked")
@@ -971,6 +1001,14 @@ def conv1x1_dgrad(dy, weight, mask_cols=None):
     return _conv1x1_run(dy, mask_cols, weight, _const(dy.device, "zeros", int(weight.shape[1])), True)
 
 
+def _wgrad_small(x, mask_cols, dy, dw, db, ksize):
+    B, cin, H, W = x.shape
+    cout = int(dy.shape[1])
+    scratch = torch.empty(int(lib().gtts_conv_wgrad_small_scratch_floats(B, cin, cout, ksize)), dtype=torch.float32, device=x.device)
+    _check(lib().gtts_conv_wgrad_small(_ptr(x), _ptr(mask_cols), _ptr(dy), _ptr(dw), _ptr(db), _ptr(scratch), B, cin, cout, H, W, ksize,
+                                       _stream()), "gtts_conv_wgrad_small")
+
+
 def conv1x1_wgrad(x, mask_cols, dy, want_bias=True):
     """(dW [cout,cin,1,1], db [cout] or None) of conv1x1_masked."""
     x, dy = _f32c(x, "x"), _f32c(dy, "dy")
@@ -978,7 +1016,11 @@ def conv1x1_wgrad(x, mask_cols, dy, want_bias=True):
     cout = int(dy.shape[1])
     dw = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=x.device)
     db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_bias else None
-    with torch.cuda.device(x.device):
+    if cin in (2, 3):
+        with _on(x.device):
+            _wgrad_small(x, _const(x.device, "ones", B, W) if mask_cols is None else _f32c(mask_cols, "mask"), dy, dw, db, 1)
+        return dw, db
+    with _on(x.device):
         nws = int(lib().gtts_conv1x1_wgrad_workspace_bytes(B, cin, cout, H, W))
         ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
         _check(lib().gtts_conv1x1_wgrad(_ptr(x), _ptr(_f32c(mask_cols, "mask")) if mask_cols is not None else None, _ptr(dy), _ptr(dw),
@@ -994,9 +1036,19 @@ def add_masked(a, b, mask_cols, channels=None):
     B, Cb, H, W = b.shape
     c0, c1 = (0, Cb) if channels is None else channels
     out = torch.empty((B, c1 - c0, H, W), dtype=torch.float32, device=b.device)
-    with torch.cuda.device(b.device):
+    with _on(b.device):
         _check(lib().gtts_add_masked(_ptr(a), ctypes.c_void_p(b.data_ptr() + 4 * c0 * H * W), _ptr(mask_cols), _ptr(out), B, c1 - c0, H, W,
                                      0 if channels is None else Cb, _stream()), "gtts_add_masked")
+    return out
+
+
+def zero_insert2(x):
+    """[B,C,h,w] -> [B,C,2h,2w] with x at the even positions and zeros elsewhere."""
+    x = _f32c(x, "x")
+    B, C, h, w = x.shape
+    out = torch.empty((B, C, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    with _on(x.device):
+        _check(lib().gtts_zero_insert2(_ptr(x), _ptr(out), B, C, h, w, _stream()), "gtts_zero_insert2")
     return out
 
 
@@ -1005,7 +1057,7 @@ def final_conv_forward(x, weight, bias, mask_cols):
     x, weight, bias, mask_cols = _f32c(x, "x"), _f32c(weight, "weight"), _f32c(bias, "bias"), _f32c(mask_cols, "mask")
     B, C, H, W = x.shape
     out = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _check(lib().gtts_final_conv_forward(_ptr(x), _ptr(weight), _ptr(bias), _ptr(mask_cols), _ptr(out), B, C, H, W, _stream()),
                "gtts_final_conv_forward")
     return out
@@ -1018,7 +1070,7 @@ def final_conv_backward(x, weight, mask_cols, dout):
     dx = torch.empty_like(x)
     dw = torch.empty((1, C, 1, 1), dtype=torch.float32, device=x.device)
     db = torch.empty((1,), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         scratch = torch.empty(int(lib().gtts_final_conv_scratch_floats(B, C, H, W)), dtype=torch.float32, device=x.device)
         _check(lib().gtts_final_conv_backward(_ptr(x), _ptr(weight), _ptr(mask_cols), _ptr(dout), _ptr(dx), _ptr(dw), _ptr(db),
                                               _ptr(scratch), B, C, H, W, _stream()), "gtts_final_conv_backward")
@@ -1043,7 +1095,7 @@ def conv_resample(x, mask_cols, weight, bias, up, dgrad_of_down=False):
         cout, kind = (int(weight.shape[1]), "up") if up else (int(weight.shape[0]), "dn")
     bias = _const(x.device, "zeros", cout) if bias is None else _f32c(bias, "bias")
     y = torch.empty((B, cout, 2 * H, 2 * W) if up else (B, cout, H // 2, W // 2), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         packed = _packed_weight(weight, cin, cout, False, kind)
         _check(lib().gtts_conv_resample(_ptr(x), _ptr(mask_cols), _ptr(packed), _ptr(bias), _ptr(y), B, cin, cout, H, W, 1 if up else 0,
                                         _stream()), "gtts_conv_resample")
@@ -1061,7 +1113,7 @@ def attn_train_forward(qkv):
     out = torch.empty((B, 128, H, W), dtype=torch.float32, device=qkv.device)
     ctx = torch.empty((B, 4, 32, 32), dtype=torch.float32, device=qkv.device)
     stat = torch.empty((B, 4, 32, 2), dtype=torch.float32, device=qkv.device)
-    with torch.cuda.device(qkv.device):
+    with _on(qkv.device):
         scratch = torch.empty(int(lib().gtts_attn_train_scratch_floats(B, N)), dtype=torch.float32, device=qkv.device)
         _check(lib().gtts_attn_train_forward(_ptr(qkv), _ptr(out), _ptr(ctx), _ptr(stat), _ptr(scratch), B, N, _stream()),
                "gtts_attn_train_forward")
@@ -1076,7 +1128,7 @@ def attn_train_backward(qkv, dout, ctx, stat):
     dqkv = torch.empty_like(qkv)
     dctx = torch.empty((B, 4, 32, 32), dtype=torch.float32, device=qkv.device)
     rdot = torch.empty((B, 4, 32), dtype=torch.float32, device=qkv.device)
-    with torch.cuda.device(qkv.device):
+    with _on(qkv.device):
         scratch = torch.empty(int(lib().gtts_attn_train_scratch_floats(B, N)), dtype=torch.float32, device=qkv.device)
         _check(lib().gtts_attn_train_backward(_ptr(qkv), _ptr(dout), _ptr(ctx), _ptr(stat), _ptr(dqkv), _ptr(dctx), _ptr(rdot),
                                               _ptr(scratch), B, N, _stream()), "gtts_attn_train_backward")
@@ -1087,7 +1139,7 @@ def rezero_forward(f, g, x):
     """f * g + x (Rezero + Residual, diffusion.py:40-46,103-108); g a 1-element device tensor."""
     f, x, g = _f32c(f, "f"), _f32c(x, "x"), _f32c(g, "g")
     y = torch.empty_like(f)
-    with torch.cuda.device(f.device):
+    with _on(f.device):
         _check(lib().gtts_rezero_forward(_ptr(f), _ptr(x), _ptr(g), _ptr(y), f.numel(), _stream()), "gtts_rezero_forward")
     return y
 
@@ -1097,7 +1149,7 @@ def rezero_backward(dy, f, g):
     dy, f, g = _f32c(dy, "dy"), _f32c(f, "f"), _f32c(g, "g")
     df = torch.empty_like(f)
     dg = torch.empty_like(g)
-    with torch.cuda.device(f.device):
+    with _on(f.device):
         scratch = torch.empty(int(lib().gtts_rezero_scratch_bytes(f.numel())), dtype=torch.uint8, device=f.device)
         _check(lib().gtts_rezero_backward(_ptr(dy), _ptr(f), _ptr(g), _ptr(df), _ptr(dg), _ptr(scratch), f.numel(), _stream()),
                "gtts_rezero_backward")
@@ -1111,7 +1163,7 @@ def gn_mish_forward(y, gamma, beta, mask_cols, groups, eps, tb=None):
     B, C, H, W = y.shape
     out = torch.empty_like(y)
     stats = torch.empty(int(lib().gtts_gn_mish_stats_floats(B, int(groups))), dtype=torch.float32, device=y.device)
-    with torch.cuda.device(y.device):
+    with _on(y.device):
         _check(lib().gtts_gn_mish_forward_tb(_ptr(y), _ptr(gamma), _ptr(beta), _ptr(mask_cols), _ptr(tb), _ptr(out), _ptr(stats), B, C,
                                              H, W, int(groups), float(eps), _stream()), "gtts_gn_mish_forward")
     return out, stats
@@ -1126,7 +1178,7 @@ def gn_mish_backward(dout, y, gamma, beta, mask_cols, stats, groups, want_dtb=Fa
     db = torch.empty((C,), dtype=torch.float32, device=y.device)
     dtb = torch.empty((B, C), dtype=torch.float32, device=y.device) if want_dtb else None
     scratch = torch.empty(int(lib().gtts_gn_mish_scratch_bytes(B, C)), dtype=torch.uint8, device=y.device)
-    with torch.cuda.device(y.device):
+    with _on(y.device):
         _check(lib().gtts_gn_mish_backward_tb(_ptr(dout), _ptr(y), _ptr(_f32c(gamma, "gamma")), _ptr(_f32c(beta, "beta")),
                                               _ptr(_f32c(mask_cols, "mask")), _ptr(stats), _ptr(dy), _ptr(dg), _ptr(db), _ptr(dtb),
                                               _ptr(scratch), B, C, H, W, int(groups), _stream()), "gtts_gn_mish_backward")
@@ -1138,7 +1190,7 @@ def diffusion_noising(x0, mu, z, mask, t, beta_min, beta_max):
     x0, mu, z, mask, t = (_f32c(v, n) for v, n in ((x0, "x0"), (mu, "mu"), (z, "z"), (mask, "mask"), (t, "t")))
     B, F, T = x0.shape
     xt, zm = torch.empty_like(x0), torch.empty_like(x0)
-    with torch.cuda.device(x0.device):
+    with _on(x0.device):
         _check(lib().gtts_diffusion_noising(_ptr(x0), _ptr(mu), _ptr(z), _ptr(mask), _ptr(t), float(beta_min), float(beta_max),
                                             _ptr(xt), _ptr(zm), B, F, T, _stream()), "gtts_diffusion_noising")
     return xt, zm
@@ -1156,7 +1208,7 @@ def score_loss(eps, z_masked, t, beta_min, beta_max, inv_denom, want_grad=True):
     n = int(lib().gtts_score_loss_partials(B, F, T))
     part = torch.empty(n, dtype=torch.float32, device=eps.device)
     g = torch.empty_like(eps) if want_grad else None
-    with torch.cuda.device(eps.device):
+    with _on(eps.device):
         _check(lib().gtts_score_loss(_ptr(eps), _ptr(z_masked), _ptr(t), float(beta_min), float(beta_max), float(inv_denom),
                                      _ptr(part), _ptr(g), B, F, T, _stream()), "gtts_score_loss")
     return part.sum() * inv_denom, g
@@ -1172,7 +1224,7 @@ def log_prior(mu_x, y):
         raise RuntimeError("mu_x [B,F,t_x] and y [B,F,T] disagree: %s vs %s" % (tuple(mx.shape), tuple(yy.shape)))
     T = yy.shape[2]
     out = torch.empty((B, tx, T), dtype=torch.float32, device=mx.device)
-    with torch.cuda.device(mx.device):
+    with _on(mx.device):
         _check(lib().gtts_log_prior(_ptr(mx), _ptr(yy), _ptr(out), B, F, tx, T, _stream()), "gtts_log_prior")
     return out
 
@@ -1195,7 +1247,7 @@ def expand_alignment(duration, x_mask, y_lengths, mu_x, T, noise=None, temperatu
     attn = torch.empty((B, tx, T), dtype=torch.float32, device=mx.device)
     mu_y = torch.empty((B, F, T), dtype=torch.float32, device=mx.device)
     z = torch.empty((B, F, T), dtype=torch.float32, device=mx.device) if nz is not None else None
-    with torch.cuda.device(mx.device):
+    with _on(mx.device):
         _check(lib().gtts_expand_alignment(_ptr(d), _ptr(m), _ptr(yl), _ptr(mx), _ptr(nz), float(temperature), _ptr(attn),
                                            _ptr(mu_y), _ptr(z), B, F, tx, int(T), _stream()), "gtts_expand_alignment")
     return attn, mu_y, z

@@ -31,6 +31,91 @@ __global__ __launch_bounds__(256) void add_masked_kernel(const float *__restrict
     }
 }
 
+// grid (B * C, ceil(4hw / 1024)): out [2h][2w] = in [h][w] at the even (row, column) positions, zero elsewhere.  The weight
+// gradient of a stride-2 convolution is the stride-1 weight gradient against the zero-inserted output gradient.
+__global__ __launch_bounds__(256) void zero_insert2_kernel(const float *__restrict__ in, float *__restrict__ out, int h, int w) {
+    const size_t bc = blockIdx.x;
+    const int W2 = 2 * w, n = 4 * h * w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = blockIdx.y * 1024 + k * 256 + threadIdx.x;
+        if (i < n) {
+            const int y = i / W2, x = i - y * W2;
+            out[bc * n + i] = ((y | x) & 1) ? 0.f : in[bc * (size_t)(h * w) + (size_t)(y >> 1) * w + (x >> 1)];
+        }
+    }
+}
+
+// First-layer weight gradient (the stacked (mu, x[, spk]) input: cin = 2 or 3; diffusion.py:140-147): a GEMM with K <= 27 is
+// no MFMA job -- it is one pass over dy.  grid (cout / 4, B, WS_SPLIT): a thread sums, over its pixels of the slice, the
+// products of four channels' dy[co,p] with the (x m)[ci, p + tap] neighbourhood it loads once (x is 2-3 planes, cache
+// resident) into 4 x (cin * taps + 1) registers; the workgroup reduces them in a fixed order into part[b][slice][co][cin*taps + 1]
+// (last: the bias gradient).
+constexpr int WS_SPLIT = 4, WS_CO = 4;
+template <int CIN, int K>
+__global__ __launch_bounds__(256) void wgrad_small_kernel(const float *__restrict__ x, const float *__restrict__ mask, const float *__restrict__ dy,
+                                                          float *__restrict__ part, int cout, int H, int W) {
+    constexpr int NT = CIN * K * K, R = K / 2;
+    const int co0 = blockIdx.x * WS_CO, bi = blockIdx.y, sl = blockIdx.z, HW = H * W;
+    const float *pd = dy + ((size_t)bi * cout + co0) * HW;
+    const float *px = x + (size_t)bi * CIN * HW;
+    const float *mrow = mask + (size_t)bi * W;
+    float acc[WS_CO][NT + 1];
+#pragma unroll
+    for (int c = 0; c < WS_CO; ++c)
+#pragma unroll
+        for (int i = 0; i <= NT; ++i) acc[c][i] = 0.f;
+    const int per = (HW + WS_SPLIT - 1) / WS_SPLIT, p_end = min(HW, (sl + 1) * per);
+    for (int p = sl * per + threadIdx.x; p < p_end; p += 256) {
+        const int y = p / W, xx = p - y * W;
+        float g[WS_CO];
+#pragma unroll
+        for (int c = 0; c < WS_CO; ++c) {
+            g[c] = pd[(size_t)c * HW + p];
+            acc[c][NT] += g[c];
+        }
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const int yy = y + ky - R, xc = xx + kx - R;
+                    const bool in = yy >= 0 && yy < H && xc >= 0 && xc < W;
+                    const float v = in ? px[(size_t)ci * HW + (size_t)yy * W + xc] * mrow[xc] : 0.f;
+#pragma unroll
+                    for (int c = 0; c < WS_CO; ++c) acc[c][(ci * K + ky) * K + kx] = fmaf(g[c], v, acc[c][(ci * K + ky) * K + kx]);
+                }
+    }
+    // fixed-order reduction: butterfly inside each wave, then the four waves through LDS
+    __shared__ float s_w[4][WS_CO * (NT + 1)];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < WS_CO; ++c)
+#pragma unroll
+        for (int i = 0; i <= NT; ++i) {
+            float v = acc[c][i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) s_w[wave][c * (NT + 1) + i] = v;
+        }
+    __syncthreads();
+    for (int e = threadIdx.x; e < WS_CO * (NT + 1); e += 256) {
+        const int c = e / (NT + 1), i = e - c * (NT + 1);
+        part[(((size_t)bi * WS_SPLIT + sl) * cout + co0 + c) * (NT + 1) + i] = (s_w[0][e] + s_w[1][e]) + (s_w[2][e] + s_w[3][e]);
+    }
+}
+// dw[co][ci][ky][kx] (reference layout) and db[co]: sum of the per-sample records in sample order; one thread per element
+__global__ void wgrad_small_finish_kernel(const float *__restrict__ part, float *__restrict__ dw, float *__restrict__ db, int B, int cout, int nt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cout * (nt + 1)) return;
+    const int co = i / (nt + 1), e = i - co * (nt + 1);
+    double t = 0.0;
+    for (int b = 0; b < B; ++b) t += (double)part[((size_t)b * cout + co) * (nt + 1) + e];
+    if (e < nt) dw[(size_t)co * nt + e] = (float)t;
+    else if (db) db[co] = (float)t;
+}
+
 // final_conv: out[b,p] = (sum_c w[c] x[b,c,p] m + bias) m,  m = mask[b, p % W]   (diffusion.py:175-176); grid (ceil(HW/256), B)
 __global__ __launch_bounds__(256) void final_conv_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                                                              const float *__restrict__ mask, float *__restrict__ out, int C, int HW, int W) {
@@ -123,6 +208,39 @@ extern "C" int gtts_add_masked(const float *a, const float *b, const float *mask
     const int HW = H * W;
     hipLaunchKernelGGL(add_masked_kernel, dim3(B * C, (HW + 1023) / 1024), dim3(256), 0, (hipStream_t)stream, a, b, mask, out, C, HW, W,
                        (size_t)(b_cstride > 0 ? b_cstride : C) * HW);
+    ECHK(hipGetLastError());
+    return GTTS_OK;
+}
+
+extern "C" size_t gtts_conv_wgrad_small_scratch_floats(int B, int cin, int cout, int ksize) {
+    if (B <= 0 || cin <= 0 || cout <= 0) return 0;
+    return (size_t)B * WS_SPLIT * cout * (cin * ksize * ksize + 1);
+}
+
+// dw [cout][cin][k][k], db [cout] (nullable) of y = Conv2d_kxk(x * mask) + bias for the first layer: cin 2 or 3, k 3 or 1
+extern "C" int gtts_conv_wgrad_small(const float *x, const float *mask, const float *dy, float *dw, float *db, float *scratch, int B, int cin,
+                                     int cout, int H, int W, int ksize, gtts_stream_t stream) {
+    if (!x || !mask || !dy || !dw || !scratch) return efail(GTTS_E_NULL, "gtts_conv_wgrad_small: null argument");
+    if (B <= 0 || cout <= 0 || cout % WS_CO || H <= 0 || W <= 0 || (cin != 2 && cin != 3) || (ksize != 1 && ksize != 3))
+        return efail(GTTS_E_SHAPE, "gtts_conv_wgrad_small: cin must be 2 or 3 and the kernel 1x1 or 3x3 (got cin %d, k %d)", cin, ksize);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(cout / WS_CO, B, WS_SPLIT);
+    if (cin == 2 && ksize == 3) hipLaunchKernelGGL((wgrad_small_kernel<2, 3>), grid, dim3(256), 0, st, x, mask, dy, scratch, cout, H, W);
+    else if (cin == 3 && ksize == 3) hipLaunchKernelGGL((wgrad_small_kernel<3, 3>), grid, dim3(256), 0, st, x, mask, dy, scratch, cout, H, W);
+    else if (cin == 2) hipLaunchKernelGGL((wgrad_small_kernel<2, 1>), grid, dim3(256), 0, st, x, mask, dy, scratch, cout, H, W);
+    else hipLaunchKernelGGL((wgrad_small_kernel<3, 1>), grid, dim3(256), 0, st, x, mask, dy, scratch, cout, H, W);
+    ECHK(hipGetLastError());
+    const int nt = cin * ksize * ksize;
+    hipLaunchKernelGGL(wgrad_small_finish_kernel, dim3((cout * (nt + 1) + 255) / 256), dim3(256), 0, st, scratch, dw, db, B * WS_SPLIT, cout, nt);
+    ECHK(hipGetLastError());
+    return GTTS_OK;
+}
+
+// out [B,C,2h,2w] = in [B,C,h,w] at the even positions, zero elsewhere
+extern "C" int gtts_zero_insert2(const float *in, float *out, int B, int C, int h, int w, gtts_stream_t stream) {
+    if (!in || !out) return efail(GTTS_E_NULL, "gtts_zero_insert2: null argument");
+    if (B <= 0 || C <= 0 || h <= 0 || w <= 0 || (long)h * w >= (1l << 28)) return efail(GTTS_E_SHAPE, "gtts_zero_insert2: bad shape");
+    hipLaunchKernelGGL(zero_insert2_kernel, dim3(B * C, (4 * h * w + 1023) / 1024), dim3(256), 0, (hipStream_t)stream, in, out, h, w);
     ECHK(hipGetLastError());
     return GTTS_OK;
 }

@@ -9,8 +9,8 @@ csrc/train*.hip behind torch.autograd.Function wrappers:
   MaskedConv1x1        res_conv, to_qkv, to_out (forward / data gradient on the CONV_P1 kernel, MFMA weight gradient)
   LinearAttentionCore  softmax over pixels, context, output (forward and backward)
   RezeroResidual, MaskedResidualAdd, the plain residual add, FinalConv (64 -> 1 with both masks), ScoreLoss
-  DownConv / UpConv    Downsample / Upsample forward (and Downsample's data gradient) on the inference kernels; their weight
-                       gradients and Upsample's data gradient are the one part left on MIOpen (aten.convolution_backward)
+  ResampleConv         Downsample / Upsample forward and all of Downsample's gradients on the HIP kernels; Upsample's gradients
+                       are the one part left on MIOpen (aten.convolution_backward)
 The [B, dim] time / speaker MLPs stay stock torch ops.  On CPU tensors (tests) everything is stock torch.
 """
 import math
@@ -167,7 +167,8 @@ class FinalConv(torch.autograd.Function):
 
 class ResampleConv(torch.autograd.Function):
     """Downsample / Upsample of x * mask (diffusion.py:19-34,158,171): forward on the inference kernels; Downsample's data
-    gradient is an Upsample call with the zero-padded kernel; the weight gradients and Upsample's data gradient are MIOpen's."""
+    gradient is an Upsample call with the zero-padded kernel and its weight gradient the stride-1 MFMA reduction against the
+    zero-inserted dy; Upsample's gradients are MIOpen's (aten.convolution_backward)."""
 
     @staticmethod
     def forward(ctx, x, mask, weight, bias, up):
@@ -182,17 +183,19 @@ class ResampleConv(torch.autograd.Function):
         be = backend()
         x, cols, weight = ctx.saved_tensors
         dy = dy.contiguous()
-        xm = be.add_masked(None, x, cols)
         need_dx = ctx.needs_input_grad[0]
-        aten_dx = need_dx and ctx.up
-        gi, gw, gb = torch.ops.aten.convolution_backward(dy, xm, weight, [ctx.bias_n], [2, 2], [1, 1], [1, 1], ctx.up, [0, 0], 1,
-                                                         [aten_dx, True, True])
-        dx = None
-        if need_dx:
-            if not ctx.up:
+        if not ctx.up:
+            # stride 2: the weight gradient is the stride-1 one against the zero-inserted dy (MFMA reduction of train_wgrad.hip)
+            gw, gb = be.conv3x3_wgrad(x, cols, be.zero_insert2(dy))
+            gi = None
+            if need_dx:
                 ones = be._const(dy.device, "ones", int(dy.shape[0]), int(dy.shape[3]))
                 gi = be.conv_resample(dy, ones, weight, None, True, dgrad_of_down=True)
-            dx = be.add_masked(None, gi, cols)
+        else:
+            xm = be.add_masked(None, x, cols)
+            gi, gw, gb = torch.ops.aten.convolution_backward(dy, xm, weight, [ctx.bias_n], [2, 2], [1, 1], [1, 1], True, [0, 0], 1,
+                                                             [need_dx, True, True])
+        dx = be.add_masked(None, gi, cols) if need_dx else None
         return dx, None, gw, gb, None
 
 
@@ -216,7 +219,7 @@ FORCE_TORCH = False      # measurement switch (bench.py train_step): route every
 
 def _hip_conv_ok(v, conv):
     return (not FORCE_TORCH and v.is_cuda and v.dtype == torch.float32 and conv.kernel_size == (3, 3) and
-            backend().conv3x3_supported(conv.in_channels, conv.out_channels))
+            backend().conv3x3_supported(conv.in_channels, conv.out_channels, need_dgrad=v.requires_grad))
 
 
 def _conv1x1(v, m, conv):
@@ -252,10 +255,22 @@ def _conv_gn_mish(blk, v, m, tb=None, v1=None):
     return y if tb is None else y + tb[:, :, None, None]
 
 
-def resnet(rb, v, m, temb, v1=None):
-    """ResnetBlock.forward (diffusion.py:73-78) on v, or on cat(v, v1) without materialising it."""
-    lin = rb.mlp[1]
-    tb = F.linear(_mish(temb), lin.weight, lin.bias)
+def time_terms(blocks, temb):
+    """ResnetBlock.mlp (Mish -> Linear, diffusion.py:66-67,75) of every block in one pass: Mish(temb) once, one Linear over the
+    concatenated weights; returns the per-block [B, dim_out] terms (views).  The 12 blocks share the same input, and 36 separate
+    [16 x 64] GEMMs and 80 elementwise launches cost more than the attention layers."""
+    mt = _mish(temb)
+    lins = [rb.mlp[1] for rb in blocks]
+    tb = F.linear(mt, torch.cat([l.weight for l in lins], dim=0), torch.cat([l.bias for l in lins], dim=0))
+    return list(torch.split(tb, [l.out_features for l in lins], dim=1))
+
+
+def resnet(rb, v, m, temb, v1=None, tb=None):
+    """ResnetBlock.forward (diffusion.py:73-78) on v, or on cat(v, v1) without materialising it.  tb: the block's time term if the
+    caller has computed it (time_terms)."""
+    if tb is None:
+        lin = rb.mlp[1]
+        tb = F.linear(_mish(temb), lin.weight, lin.bias)
     h = _conv_gn_mish(rb.block1, v, m, tb=tb, v1=v1)
     h = _conv_gn_mish(rb.block2, h, m)
     if isinstance(rb.res_conv, torch.nn.Conv2d):
@@ -320,20 +335,26 @@ def estimator(est, x, mask, mu, t, spk=None):
         planes.append(s[:, :, None].expand(-1, -1, x.shape[-1]))
     v = torch.stack(planes, 1)
     m = mask[:, None]
+    blocks = [rb for r1, r2, _, _ in est.downs for rb in (r1, r2)] + [est.mid_block1, est.mid_block2] + \
+             [rb for r1, r2, _, _ in est.ups for rb in (r1, r2)]
+    tbs = iter(time_terms(blocks, temb))
     skips, pyramid = [], [m]
     for r1, r2, att, down in est.downs:
         m = pyramid[-1]
-        v = attention(att, resnet(r2, resnet(r1, v, m, temb), m, temb))
+        v = resnet(r1, v, m, temb, tb=next(tbs))
+        v = attention(att, resnet(r2, v, m, temb, tb=next(tbs)))
         skips.append(v)
         if not isinstance(down, torch.nn.Identity):
             v = _resample(v, m, down.conv, False)
         pyramid.append(m[..., ::2].contiguous())        # (contiguous: every op below takes its [B, W] view without a copy)
     pyramid.pop()
     m = pyramid[-1]
-    v = resnet(est.mid_block2, attention(est.mid_attn, resnet(est.mid_block1, v, m, temb)), m, temb)
+    v = resnet(est.mid_block1, v, m, temb, tb=next(tbs))
+    v = resnet(est.mid_block2, attention(est.mid_attn, v), m, temb, tb=next(tbs))
     for r1, r2, att, up in est.ups:
         m = pyramid.pop()
-        v = attention(att, resnet(r2, resnet(r1, v, m, temb, v1=skips.pop()), m, temb))       # (torch.cat read in place)
+        v = resnet(r1, v, m, temb, v1=skips.pop(), tb=next(tbs))       # (torch.cat read in place)
+        v = attention(att, resnet(r2, v, m, temb, tb=next(tbs)))
         v = _resample(v, m, up.conv, True)
     m = mask[:, None]
     v = _conv_gn_mish(est.final_block, v, m)

@@ -52,7 +52,7 @@ def plan_for(S, dev, seed, n_spks=1):
 
 # ------------------------------------------------------------------------------------------------ library
 def test_native_library_is_loaded(S):
-    assert S._lib.lib().gtts_abi_version() == 2
+    assert S._lib.lib().gtts_abi_version() == 3
     import os
     assert os.path.exists(S._lib.LIB_PATH)
 

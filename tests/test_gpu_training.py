@@ -84,6 +84,30 @@ def test_conv1x1_forward_dgrad_wgrad(S, dev, B, cin, cout, H, W, masked, bias):
         assert float((xg.grad.cpu() * (1 - mask)).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("cin,k", [(2, 3), (3, 3), (2, 1), (3, 1)])
+def test_first_layer_conv_forward_and_weight_gradient(S, dev, cin, k):
+    """The first ResnetBlock's convolutions on the stacked (mu, x[, spk]) planes (diffusion.py:140-147): ragged-channel forward
+    on the inference kernel, weight / bias gradient on the one-pass kernel of train_elem.hip; no data gradient (inputs)."""
+    T = importlib.import_module("speech-backbones_amd.model._train_ops")
+    g = torch.Generator().manual_seed(cin + k)
+    B, cout, H, W = 3, 64, 80, 45
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = (torch.randn(cout, cin, k, k, generator=g) / (k * cin ** 0.5)).requires_grad_(True)
+    b = torch.randn(cout, generator=g).requires_grad_(True)
+    lens = torch.tensor([W, W - 7, 13])
+    mask = O.sequence_mask(lens, W).float()[:, None, None, :]
+    dy = torch.randn(B, cout, H, W, generator=g)
+    y_ref = F.conv2d(x * mask, w, b, padding=k // 2)
+    y_ref.backward(dy)
+    wg, bg = (t.detach().clone().to(dev).requires_grad_(True) for t in (w, b))
+    fn = T.MaskedConv3x3 if k == 3 else T.MaskedConv1x1
+    y = fn.apply(x.to(dev), mask.to(dev), wg, bg)
+    y.backward(dy.to(dev))
+    assert relerr(y.detach().cpu(), y_ref.detach()) <= REL
+    assert relerr(wg.grad.cpu(), w.grad) <= REL
+    assert relerr(bg.grad.cpu(), b.grad) <= REL
+
+
 @pytest.mark.parametrize("B,C,H,W", [(2, 64, 80, 44), (3, 128, 40, 43), (1, 256, 20, 13), (4, 64, 7, 150)])
 def test_linear_attention_core_and_rezero(S, dev, B, C, H, W):
     """LinearAttention (to_qkv -> softmax over pixels -> context -> out -> to_out) under Residual(Rezero(.)) -- diffusion.py:82-108
