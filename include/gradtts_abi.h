@@ -77,6 +77,12 @@ typedef struct gtts_unet_cfg {
     int c_dim;           /* 256: speaker-embedding width                                                 */
     double vc_beta_min;  /* DiffVC schedule scalars are Python doubles in the reference (diffusion.py:120-149) */
     double vc_beta_max;
+    /* ---- ABI 3: which kernel runs the Block 3x3 convolutions of 128-channel-and-wider layers in GTTS_PREC_BF16X3 ---- */
+    int conv_ws;         /* 0: uniform-wave kernel (conv_mfma.hip; overlaps with other streams' kernels: best with three
+                            sub-batch streams on the Grad-TTS dim-64 network).  1: persistent wave-specialised kernel
+                            (conv_ws.hip; a higher MFMA rate per launch, but it fills every CU's registers: best where these
+                            convolutions dominate, e.g. the DiffVC dim-256 decoder).  Either way results do not depend on
+                            the batch split; the two modes agree to fp32 rounding of the GroupNorm statistics. */
 } gtts_unet_cfg;
 
 typedef struct gtts_plan gtts_plan;   /* host-side metadata only */

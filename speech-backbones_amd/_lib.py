@@ -27,7 +27,7 @@ class UnetCfg(ctypes.Structure):
                 ("beta_min", ctypes.c_float), ("beta_max", ctypes.c_float), ("precision", ctypes.c_int),
                 ("keep_intermediates", ctypes.c_int), ("arch", ctypes.c_int), ("dim_cond", ctypes.c_int),
                 ("use_ref_t", ctypes.c_int), ("c_dim", ctypes.c_int), ("vc_beta_min", ctypes.c_double),
-                ("vc_beta_max", ctypes.c_double)]
+                ("vc_beta_max", ctypes.c_double), ("conv_ws", ctypes.c_int)]
 
 
 class EncCfg(ctypes.Structure):
@@ -233,26 +233,36 @@ class Plan:
 
     def __init__(self, dim=64, n_feats=80, n_spks=1, spk_emb_dim=64, groups=8, pe_scale=1000.0, beta_min=0.05,
                  beta_max=20.0, precision=PREC_BF16X3, keep_intermediates=False, arch=0, dim_cond=128, use_ref_t=True,
-                 c_dim=256, streams=None):
+                 c_dim=256, streams=None, conv_ws=None):
         """arch=0: Grad-TTS GradLogPEstimator2d; arch=1: DiffVC GradLogPEstimator (dim = dim_base).
 
+        conv_ws: which kernel runs the wide Block 3x3 convolutions in bf16x3 (gtts_unet_cfg.conv_ws).  False: the uniform-wave
+        kernel of conv_mfma.hip, which shares CUs with other streams' kernels.  True: the persistent wave-specialised kernel of
+        conv_ws.hip -- 11 % faster per launch, but it owns every CU's registers while it runs.  None (default): True where these
+        convolutions dominate (dim >= 128: the DiffVC decoder, +6 % end to end), False on the Grad-TTS dim-64 network, where a
+        third of the call is bandwidth-bound kernels that three sub-batch streams hide under the convolutions of another
+        sub-batch (measured on one box: 7.05 ms per U-Net call against 7.47 with the persistent kernel on two streams).
+
         streams: number of sub-batches gtts_reverse_diffusion runs side by side on torch side streams owned by this
-        object and registered with gtts_plan_set_streams (0 / 1: no split; $GTTS_STREAMS overrides the default).  Default 2 for
-        bf16x3: the persistent Block convolutions fill the chip in whole rounds with 8 + 8 utterances and leave nothing to
-        overlap inside themselves, the second stream overlaps the bandwidth-bound kernels in between.  Default 3 for the
-        single-pass bf16 modes, whose convolutions are conv_mfma.hip's and overlap well."""
+        object and registered with gtts_plan_set_streams (0 / 1: no split; $GTTS_STREAMS overrides the default).  Default 3;
+        2 with conv_ws (8 + 8 utterances fill the chip in whole rounds of persistent workgroups)."""
+        if conv_ws is None:
+            conv_ws = int(dim) >= 128
+        conv_ws = bool(conv_ws) and int(precision) == PREC_BF16X3
         self._kw = dict(dim=dim, n_feats=n_feats, n_spks=n_spks, spk_emb_dim=spk_emb_dim, groups=groups,
                         pe_scale=pe_scale, beta_min=beta_min, beta_max=beta_max, precision=precision,
                         keep_intermediates=keep_intermediates, arch=arch, dim_cond=dim_cond, use_ref_t=use_ref_t,
-                        c_dim=c_dim, streams=streams)
+                        c_dim=c_dim, streams=streams, conv_ws=conv_ws)
+        self.conv_ws = conv_ws
         self.cfg = UnetCfg(int(dim), int(n_feats), int(n_spks), int(spk_emb_dim), int(groups), float(pe_scale),
                            float(beta_min), float(beta_max), int(precision), 1 if keep_intermediates else 0, int(arch),
-                           int(dim_cond), 1 if use_ref_t else 0, int(c_dim), float(beta_min), float(beta_max))
+                           int(dim_cond), 1 if use_ref_t else 0, int(c_dim), float(beta_min), float(beta_max),
+                           1 if conv_ws else 0)
         self._h = ctypes.c_void_p()
         _check(lib().gtts_plan_create(ctypes.byref(self.cfg), ctypes.byref(self._h)), "gtts_plan_create")
         self._ws = {}
         if streams is None:
-            streams = int(os.environ.get("GTTS_STREAMS", "2" if int(precision) == PREC_BF16X3 else "3"))
+            streams = int(os.environ.get("GTTS_STREAMS", "2" if conv_ws else "3"))
         self._nstreams = 0 if int(streams) < 2 else min(int(streams), 4)
         self._side = None           # (device, [torch.cuda.Stream])
         self._graph = False

@@ -630,6 +630,9 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
                             acc[mi][ni][0] += __builtin_bit_cast(float, (p[0] ^ p[1] ^ p[2] ^ p[3] ^ q[0] ^ q[1] ^ q[2] ^ q[3]) & 0x3fffffffu);
                         }
 #else
+                    // (Issuing the three bf16x3 passes pass-major over the four accumulators, pinned with sched_barrier -- every
+                    // same-accumulator pair then exactly four issue slots apart instead of hipcc's mix of 2..8 -- measured
+                    // 7.164 vs 7.176 ms per U-Net call over three alternating repeats: no difference; not kept.)
 #pragma unroll
                     for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
@@ -982,7 +985,7 @@ static hipError_t launch_prec(const ConvArgs &a, hipStream_t st) {
 hipError_t launch_conv(int mode, const ConvArgs &a, hipStream_t st) {
     const bool wide = a.cout > 64;
     // Block convolutions on whole 16-channel chunks: the persistent wave-specialised kernel (conv_ws.hip)
-    if (conv_ws_eligible(mode, a.c0, a.c1, a.cout, a.pro, a.epi, a.nsplit)) return launch_conv_ws(a, st);
+    if (a.use_ws && conv_ws_eligible(mode, a.c0, a.c1, a.cout, a.pro, a.epi, a.nsplit)) return launch_conv_ws(a, st);
     switch (mode) {
         case CONV_C3:
             if (a.epi == EPI_PLAIN) {          // DiffVC RefBlock convolutions (InstanceNorm statistics are a separate pass)

@@ -202,7 +202,7 @@ static void add_block(gtts_plan *p, const std::string &pre, const std::string &t
     int part = add_tensor(p, tname + ".part", TK_PART, p->cfg.groups, lvl);
     p->tensors[part].mode = CONV_C3;
     p->tensors[part].cout = cout;
-    p->tensors[part].ws = conv_ws_eligible(CONV_C3, c0, c1, cout, pro, EPI_STATS, p->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1);
+    p->tensors[part].ws = p->cfg.conv_ws && conv_ws_eligible(CONV_C3, c0, c1, cout, pro, EPI_STATS, p->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1);
     *sc = add_tensor(p, tname + ".sc", TK_PERB, cout, 0);
     *sh = add_tensor(p, tname + ".sh", TK_PERB, cout, 0);
     Op c = blank_op(OP_CONV, tname + ".conv");
@@ -833,6 +833,7 @@ static int run_ops(const RunCtx &c) {
                 a.groups = p->cfg.groups;
                 a.eh = tptr(c, o.eh); a.esc = tptr(c, o.esc); a.esh = tptr(c, o.esh); a.eres = tptr(c, o.eres);
                 a.nsplit = nsplit;
+                a.use_ws = p->cfg.conv_ws;
                 a.act_bf16 = abf;
                 if (o.epi == EPI_STATS && o.gn_op >= 0 && !o.use_ref) {          // GroupNorm finalize rides in the epilogue
                     const Op &gn = p->ops[o.gn_op];
@@ -1432,7 +1433,8 @@ extern "C" int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, con
                 if (o.epi == EPI_TAIL || o.epi == EPI_ATTN) by += ab * B * o.cout * Ho * Wo;
                 s_kernel = conv_kernel_name(o.mode, o.c0 + o.c1, o.cout, o.pro, o.epi, plan->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1,
                                             plan->cfg.precision == GTTS_PREC_BF16_STORE, conv_small_tiles(o.mode, o.cout, Ho, Wo, B),
-                                            conv_ws_eligible(o.mode, o.c0, o.c1, o.cout, o.pro, o.epi, plan->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1), B, (int)Ho, (int)Wo, plan->cfg.groups);
+                                            plan->cfg.conv_ws && conv_ws_eligible(o.mode, o.c0, o.c1, o.cout, o.pro, o.epi, plan->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1),
+                                            B, (int)Ho, (int)Wo, plan->cfg.groups);
                 break;
             }
             case OP_GNFIN: s_kernel = "gtts::gn_finalize_kernel"; break;

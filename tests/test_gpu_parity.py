@@ -41,13 +41,18 @@ def relerr(a, b):
 _plans = {}
 
 
-def plan_for(S, dev, seed, n_spks=1):
-    key = (seed, n_spks)
+def plan_for(S, dev, seed, n_spks=1, conv_ws=False):
+    key = (seed, n_spks, conv_ws)
     if key not in _plans:
         sd = O.make_estimator_state(seed=seed, n_spks=n_spks)
-        p = S.Plan(n_spks=n_spks)
+        p = S.Plan(n_spks=n_spks, conv_ws=conv_ws)
         _plans[key] = (sd, p, p.pack(sd, dev))
     return _plans[key]
+
+
+# both kernels of the wide Block convolutions (gtts_unet_cfg.conv_ws): uniform waves (the Grad-TTS default) and the persistent
+# wave-specialised one (the DiffVC default)
+both_convs = pytest.mark.parametrize("conv_ws", [False, True], ids=["conv_mfma", "conv_ws"])
 
 
 # ------------------------------------------------------------------------------------------------ library
@@ -113,9 +118,10 @@ def test_mas_matches_compiled_reference_when_available(S, dev):
 
 
 # ------------------------------------------------------------------------------------------------ estimator
-def test_estimator_matches_reference_golden_single_speaker(S, dev):
+@both_convs
+def test_estimator_matches_reference_golden_single_speaker(S, dev, conv_ws):
     g = golden("est_1spk.npz")
-    sd, plan, blob = plan_for(S, dev, int(g["seed"]))
+    sd, plan, blob = plan_for(S, dev, int(g["seed"]), conv_ws=conv_ws)
     out = plan.estimator_forward(blob, _t(g["z"]).to(dev), _t(g["mask"]).to(dev), _t(g["mu"]).to(dev), _t(g["t"]).to(dev)).cpu()
     ref = _t(g["est"])
     assert relerr(out, ref) <= REL
@@ -123,9 +129,10 @@ def test_estimator_matches_reference_golden_single_speaker(S, dev):
     assert float((out * (1 - _t(g["mask"]))).abs().max()) == 0.0
 
 
-def test_estimator_matches_reference_golden_multi_speaker(S, dev):
+@both_convs
+def test_estimator_matches_reference_golden_multi_speaker(S, dev, conv_ws):
     g = golden("est_3ch.npz")
-    sd, plan, blob = plan_for(S, dev, int(g["seed"]), n_spks=4)
+    sd, plan, blob = plan_for(S, dev, int(g["seed"]), n_spks=4, conv_ws=conv_ws)
     out = plan.estimator_forward(blob, _t(g["z"]).to(dev), _t(g["mask"]).to(dev), _t(g["mu"]).to(dev), _t(g["t"]).to(dev),
                                  _t(g["spk"]).to(dev)).cpu()
     ref = _t(g["est"])
@@ -133,9 +140,10 @@ def test_estimator_matches_reference_golden_multi_speaker(S, dev):
     assert float((out - ref).abs().max()) <= 1e-3
 
 
+@both_convs
 @pytest.mark.parametrize("B,T", [(1, 4), (1, 36), (3, 100), (2, 128), (5, 260)])
-def test_estimator_matches_oracle_odd_shapes(S, dev, B, T):
-    sd, plan, blob = plan_for(S, dev, 0)
+def test_estimator_matches_oracle_odd_shapes(S, dev, B, T, conv_ws):
+    sd, plan, blob = plan_for(S, dev, 0, conv_ws=conv_ws)
     inp = O.make_inputs(B, T, seed=B * 100 + T)
     t = torch.linspace(0.05, 0.95, B)
     ref = O.estimator_forward(sd, inp["z"], inp["mask"], inp["mu"], t)
@@ -143,9 +151,10 @@ def test_estimator_matches_oracle_odd_shapes(S, dev, B, T):
     assert relerr(out, ref) <= REL
 
 
-def test_estimator_empty_and_tiny_utterances(S, dev):
+@both_convs
+def test_estimator_empty_and_tiny_utterances(S, dev, conv_ws):
     """Edge cases: an all-masked utterance and a 1-frame utterance inside a batch (outputs exactly 0 where masked)."""
-    sd, plan, blob = plan_for(S, dev, 0)
+    sd, plan, blob = plan_for(S, dev, 0, conv_ws=conv_ws)
     inp = O.make_inputs(3, 32, seed=9)
     mask = O.sequence_mask(torch.tensor([32, 0, 1]), 32).unsqueeze(1).float()
     t = torch.full((3,), 0.5)
@@ -166,16 +175,18 @@ def test_bad_arguments_fail_loudly(S, dev):
 
 
 # ------------------------------------------------------------------------------------------------ sampler
-def test_reverse_diffusion_ode_matches_reference_golden(S, dev):
+@both_convs
+def test_reverse_diffusion_ode_matches_reference_golden(S, dev, conv_ws):
     g = golden("rd_ode.npz")
-    sd, plan, blob = plan_for(S, dev, int(g["seed"]))
+    sd, plan, blob = plan_for(S, dev, int(g["seed"]), conv_ws=conv_ws)
     out = plan.reverse_diffusion(blob, _t(g["z"]).to(dev), _t(g["mask"]).to(dev), _t(g["mu"]).to(dev), int(g["n"])).cpu()
     assert relerr(out, _t(g["out"])) <= REL
 
 
-def test_reverse_diffusion_sde_matches_reference_golden(S, dev):
+@both_convs
+def test_reverse_diffusion_sde_matches_reference_golden(S, dev, conv_ws):
     g = golden("rd_sde.npz")
-    sd, plan, blob = plan_for(S, dev, int(g["seed"]))
+    sd, plan, blob = plan_for(S, dev, int(g["seed"]), conv_ws=conv_ws)
     out = plan.reverse_diffusion(blob, _t(g["z"]).to(dev), _t(g["mask"]).to(dev), _t(g["mu"]).to(dev), int(g["n"]),
                                  noise=_t(g["noise"]).to(dev)).cpu()
     assert relerr(out, _t(g["out"])) <= REL
@@ -229,11 +240,12 @@ def test_precision_modes_ordering(S, dev):
 
 
 # ------------------------------------------------------------------------------------------------ full size
-def test_full_size_properties(S, dev):
+@both_convs
+def test_full_size_properties(S, dev, conv_ws):
     """BASELINE config 2 shape (B=16, 80x1024): size-independent properties instead of a CPU comparison --
     finite, masked frames exactly zero, run-to-run bit-reproducible, and batch sharding is exact (utterances are
     independent: B=16 in one call == two calls of B=8)."""
-    sd, plan, blob = plan_for(S, dev, 0)
+    sd, plan, blob = plan_for(S, dev, 0, conv_ws=conv_ws)
     B, T = 16, 1024
     inp = O.make_inputs(B, T, seed=1234, ragged=True)
     z, m, mu = inp["z"].to(dev), inp["mask"].to(dev), inp["mu"].to(dev)
@@ -250,12 +262,13 @@ def test_full_size_properties(S, dev):
     assert relerr(a[3:4].cpu(), ref) <= REL
 
 
-def test_batch_size_does_not_change_results(S, dev):
+@both_convs
+def test_batch_size_does_not_change_results(S, dev, conv_ws):
     """Small launches tile the deep 3x3 layers with half-height tiles (conv_small_tiles): at T = 1024 one utterance alone
     gets them (80 workgroups per layer), a sub-batch of two does not.  The GroupNorm partial sums of those layers are kept
     per row pair, which both tilings produce identically -- so an utterance decoded alone must be BIT-identical to the same
     utterance decoded inside a batch."""
-    sd, plan, blob = plan_for(S, dev, 0)
+    sd, plan, blob = plan_for(S, dev, 0, conv_ws=conv_ws)
     B, T = 6, 1024
     inp = O.make_inputs(B, T, seed=77, ragged=True)
     z, m, mu = inp["z"].to(dev), inp["mask"].to(dev), inp["mu"].to(dev)

@@ -80,12 +80,12 @@ ATTNS = {"downs.0.2": "downs.0.1", "downs.1.2": "downs.1.1", "downs.2.2": "downs
          "ups.0.2": "ups.0.1", "ups.1.2": "ups.1.1"}
 
 
-def _run_with_taps(S, dev, sd, B, T, n_spks=1, seed=1234):
+def _run_with_taps(S, dev, sd, B, T, n_spks=1, seed=1234, conv_ws=False):
     inp = O.make_inputs(B, T, seed=seed, spk_dim=64 if n_spks > 1 else None)
     t = torch.linspace(0.15, 0.9, B)
     taps = {}
     ref = O.estimator_forward(sd, inp["z"], inp["mask"], inp["mu"], t, inp.get("spk"), taps=taps)
-    plan = S.Plan(n_spks=n_spks, keep_intermediates=True)
+    plan = S.Plan(n_spks=n_spks, keep_intermediates=True, conv_ws=conv_ws)
     blob = plan.pack(sd, dev)
     out = plan.estimator_forward(blob, inp["z"].to(dev), inp["mask"].to(dev), inp["mu"].to(dev), t.to(dev),
                                  inp["spk"].to(dev) if n_spks > 1 else None)
@@ -94,12 +94,13 @@ def _run_with_taps(S, dev, sd, B, T, n_spks=1, seed=1234):
     return inp, taps, ref, hip, out.cpu()
 
 
+@pytest.mark.parametrize("conv_ws", [False, True], ids=["conv_mfma", "conv_ws"])
 @pytest.mark.parametrize("n_spks,B,T", [(1, 2, 64), (4, 3, 100)])
-def test_every_op_output_matches_oracle_taps(S, dev, n_spks, B, T):
+def test_every_op_output_matches_oracle_taps(S, dev, n_spks, B, T, conv_ws):
     """SURVEY section 4 'kernel' row: every Block conv (*.raw), ResnetBlock tail (*.out), attention output,
     Downsample / Upsample output and the stacked input against the oracle's taps of the same call."""
     sd = O.make_estimator_state(seed=0, n_spks=n_spks)
-    inp, taps, ref, hip, out = _run_with_taps(S, dev, sd, B, T, n_spks)
+    inp, taps, ref, hip, out = _run_with_taps(S, dev, sd, B, T, n_spks, conv_ws=conv_ws)
     checked = 0
     worst = ("", 0.0)
     for name, want in taps.items():

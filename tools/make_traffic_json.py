@@ -9,6 +9,35 @@ import json
 import sys
 
 
+def demangle(name):
+    """rocprofv3 leaves the bf16 template instances mangled (its demangler does not know DF16b): restore the printed form of
+    the gtts:: kernels (int, float and __bf16 template arguments are all this library uses)."""
+    import re
+    m = re.match(r"_ZN4gtts(\d+)", name)
+    if not m:
+        return name
+    n = int(m.group(1))
+    base, rest = name[m.end():m.end() + n], name[m.end() + n:]
+    if not rest.startswith("I"):
+        return "gtts::" + base
+    args, i = [], 1
+    while i < len(rest) and rest[i] != "E":
+        if rest.startswith("Li", i):
+            j = rest.index("E", i)
+            v = rest[i + 2:j]
+            args.append("-" + v[1:] if v.startswith("n") else v)
+            i = j + 1
+        elif rest.startswith("DF16b", i):
+            args.append("__bf16")
+            i += 5
+        elif rest[i] == "f":
+            args.append("float")
+            i += 1
+        else:
+            return name
+    return "gtts::%s<%s>" % (base, ", ".join(args))
+
+
 def parse(path):
     out = {}
     with open(path) as f:
@@ -16,7 +45,7 @@ def parse(path):
         for line in f:
             parts = line.rsplit(None, 2)
             if len(parts) == 3:
-                out[parts[0].strip()] = (int(parts[1]), float(parts[2]))
+                out[demangle(parts[0].strip())] = (int(parts[1]), float(parts[2]))
     return out
 
 
