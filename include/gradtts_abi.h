@@ -332,6 +332,9 @@ int gtts_conv_resample_pack(const float *w, void *packed, int cin, int cout, int
 int gtts_conv_resample(const float *x, const float *mask, const void *packed, const float *bias, float *y, int B, int cin, int cout,
                        int H, int W, int up, gtts_stream_t stream);
 int gtts_zero_insert2(const float *in, float *out, int B, int C, int h, int w, gtts_stream_t stream);
+/* out [B,4C,h,w] = the four stride-2 phases of in [B,C,2h,2w], channel block (pr * 2 + pc) = rows 2y + 1 - pr, columns 2x + 1 - pc:
+ * Upsample's data / weight gradient are the 3x3 stride-1 convolution / weight gradient over these planes. */
+int gtts_space_to_depth2(const float *in, float *out, int B, int C, int h, int w, gtts_stream_t stream);
 /* GroupNorm + Mish + mask with ResnetBlock's time term: out = Mish(GroupNorm(y)) * mask + tb[b,c] (tb, dtb [B][C], nullable). */
 int gtts_gn_mish_forward_tb(const float *y, const float *gamma, const float *beta, const float *mask, const float *tb, float *out,
                             float *stats, int B, int C, int H, int W, int groups, float eps, gtts_stream_t stream);

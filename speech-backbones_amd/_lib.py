@@ -113,6 +113,7 @@ def lib():
         L.gtts_conv_wgrad_small_scratch_floats.restype = sz
         L.gtts_conv_wgrad_small.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
         L.gtts_zero_insert2.argtypes = [vp, vp, i, i, i, i, vp]
+        L.gtts_space_to_depth2.argtypes = [vp, vp, i, i, i, i, vp]
         L.gtts_final_conv_forward.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp]
         L.gtts_final_conv_scratch_floats.argtypes = [i, i, i, i]
         L.gtts_final_conv_scratch_floats.restype = sz
@@ -1059,6 +1060,18 @@ def zero_insert2(x):
     out = torch.empty((B, C, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
     with _on(x.device):
         _check(lib().gtts_zero_insert2(_ptr(x), _ptr(out), B, C, h, w, _stream()), "gtts_zero_insert2")
+    return out
+
+
+def space_to_depth2(x):
+    """[B,C,2h,2w] -> [B,4C,h,w]: channel block (pr * 2 + pc) holds rows 2y + 1 - pr and columns 2x + 1 - pc."""
+    x = _f32c(x, "x")
+    B, C, H2, W2 = x.shape
+    if H2 % 2 or W2 % 2:
+        raise ValueError("space_to_depth2: even height and width expected, got %d x %d" % (H2, W2))
+    out = torch.empty((B, 4 * C, H2 // 2, W2 // 2), dtype=torch.float32, device=x.device)
+    with _on(x.device):
+        _check(lib().gtts_space_to_depth2(_ptr(x), _ptr(out), B, C, H2 // 2, W2 // 2, _stream()), "gtts_space_to_depth2")
     return out
 
 

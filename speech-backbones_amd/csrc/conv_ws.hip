@@ -752,6 +752,8 @@ static hipError_t launch_ws_ring(ConvArgs &a, hipStream_t st) {
     // persistent workgroups: one per CU for the eight-wave form; the three-wave form fits two per CU (registers: 8 waves)
     const int per_cu = C::NCW == 4 ? 1 : (int)std::min<size_t>(2, (size_t)160 * 1024 / smem);
     const long ntiles = (long)a.B * a.tiles_x * a.tiles_y * (a.cout / C::MT);
+    // (Measured and not kept: persistent workgroups on half of the CUs per launch -- grid 128 with two sub-batch streams, so
+    // that the other stream's kernels find free CUs: 7.45 vs 7.48 ms per call; the dispatcher fills the same CUs first.)
     const int grid = (int)std::min<long>(ntiles, (long)cus * per_cu);
     auto kern = &conv3x3_ws_kernel<WM, WN, MF, NF, PRO, NSPLIT, AT, 3>;
     static std::atomic<size_t> attr_set[64];

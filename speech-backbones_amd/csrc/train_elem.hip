@@ -46,6 +46,23 @@ __global__ __launch_bounds__(256) void zero_insert2_kernel(const float *__restri
     }
 }
 
+// grid (B * C, ceil(hw / 256)): the four stride-2 phases of in [B,C,2h,2w] as channel blocks of out [B,4C,h,w]:
+// out[(pr * 2 + pc) * C + c][y][x] = in[c][2y + 1 - pr][2x + 1 - pc]   (pr / pc = 1: even rows / columns).
+// Upsample's gradients are stride-1 3x3 convolutions / weight gradients over these planes (model/_train_ops.py: ResampleConv).
+__global__ __launch_bounds__(256) void space_to_depth2_kernel(const float *__restrict__ in, float *__restrict__ out, int C, int h, int w) {
+    const int bc = blockIdx.x, bi = bc / C, c = bc - bi * C;
+    const int i = blockIdx.y * 256 + threadIdx.x;
+    if (i >= h * w) return;
+    const int y = i / w, x = i - y * w;
+    const float *p = in + (size_t)bc * 4 * h * w + (size_t)(2 * y) * (2 * w) + 2 * x;      // rows 2y, 2y + 1 of the 2h x 2w plane
+    const float2 r0 = *reinterpret_cast<const float2 *>(p), r1 = *reinterpret_cast<const float2 *>(p + 2 * w);
+    const size_t plane = (size_t)h * w, base = ((size_t)bi * 4 * C + c) * plane + i;
+    out[base + (size_t)(3 * C) * plane] = r0.x;      // pr 1, pc 1: even row, even column
+    out[base + (size_t)(2 * C) * plane] = r0.y;      // pr 1, pc 0
+    out[base + (size_t)(1 * C) * plane] = r1.x;      // pr 0, pc 1
+    out[base] = r1.y;                                // pr 0, pc 0
+}
+
 // First-layer weight gradient (the stacked (mu, x[, spk]) input: cin = 2 or 3; diffusion.py:140-147): a GEMM with K <= 27 is
 // no MFMA job -- it is one pass over dy.  grid (cout / 4, B, WS_SPLIT): a thread sums, over its pixels of the slice, the
 // products of four channels' dy[co,p] with the (x m)[ci, p + tap] neighbourhood it loads once (x is 2-3 planes, cache
@@ -232,6 +249,15 @@ extern "C" int gtts_conv_wgrad_small(const float *x, const float *mask, const fl
     ECHK(hipGetLastError());
     const int nt = cin * ksize * ksize;
     hipLaunchKernelGGL(wgrad_small_finish_kernel, dim3((cout * (nt + 1) + 255) / 256), dim3(256), 0, st, scratch, dw, db, B * WS_SPLIT, cout, nt);
+    ECHK(hipGetLastError());
+    return GTTS_OK;
+}
+
+// out [B,4C,h,w] = the four stride-2 phases of in [B,C,2h,2w] (channel block (pr * 2 + pc): rows 2y + 1 - pr, columns 2x + 1 - pc)
+extern "C" int gtts_space_to_depth2(const float *in, float *out, int B, int C, int h, int w, gtts_stream_t stream) {
+    if (!in || !out) return efail(GTTS_E_NULL, "gtts_space_to_depth2: null argument");
+    if (B <= 0 || C <= 0 || h <= 0 || w <= 0 || (long)h * w >= (1l << 28)) return efail(GTTS_E_SHAPE, "gtts_space_to_depth2: bad shape");
+    hipLaunchKernelGGL(space_to_depth2_kernel, dim3(B * C, (h * w + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, out, C, h, w);
     ECHK(hipGetLastError());
     return GTTS_OK;
 }

@@ -9,8 +9,8 @@ csrc/train*.hip behind torch.autograd.Function wrappers:
   MaskedConv1x1        res_conv, to_qkv, to_out (forward / data gradient on the CONV_P1 kernel, MFMA weight gradient)
   LinearAttentionCore  softmax over pixels, context, output (forward and backward)
   RezeroResidual, MaskedResidualAdd, the plain residual add, FinalConv (64 -> 1 with both masks), ScoreLoss
-  ResampleConv         Downsample / Upsample forward and all of Downsample's gradients on the HIP kernels; Upsample's gradients
-                       are the one part left on MIOpen (aten.convolution_backward)
+  ResampleConv         Downsample / Upsample forward and all their gradients on the HIP kernels (Downsample's data gradient is an
+                       Upsample call, Upsample's gradients are 3x3 stride-1 operations over the four stride-2 phases of dy)
 The [B, dim] time / speaker MLPs stay stock torch ops.  On CPU tensors (tests) everything is stock torch.
 """
 import math
@@ -168,7 +168,7 @@ class FinalConv(torch.autograd.Function):
 class ResampleConv(torch.autograd.Function):
     """Downsample / Upsample of x * mask (diffusion.py:19-34,158,171): forward on the inference kernels; Downsample's data
     gradient is an Upsample call with the zero-padded kernel and its weight gradient the stride-1 MFMA reduction against the
-    zero-inserted dy; Upsample's gradients are MIOpen's (aten.convolution_backward)."""
+    zero-inserted dy; Upsample's gradients are the 3x3 convolution / weight gradient over the four stride-2 phases of dy."""
 
     @staticmethod
     def forward(ctx, x, mask, weight, bias, up):
@@ -192,11 +192,47 @@ class ResampleConv(torch.autograd.Function):
                 ones = be._const(dy.device, "ones", int(dy.shape[0]), int(dy.shape[3]))
                 gi = be.conv_resample(dy, ones, weight, None, True, dgrad_of_down=True)
         else:
+            # ConvTranspose2d 4x4 stride 2 pad 1: output row oy = 2 iy - 1 + ky.  Over the four stride-2 phases of dy (even / odd
+            # rows x columns, stacked as channels) both gradients are stride-1 3x3 operations: odd rows meet taps ky = 0, 2 at
+            # offsets -1, 0; even rows taps ky = 1, 3 at offsets 0, +1 (the same for columns).
+            P = be.space_to_depth2(dy)                              # [B, 4 cout, h, w], block (pr * 2 + pc), pr = 1: even rows
+            ci, co = int(weight.shape[0]), int(weight.shape[1])
+            tap = _up_tap_index(dy.device)                          # [2 (phase), 3 (ky')] -> ky, 4 = no tap
+            ones = be._const(dy.device, "ones", int(dy.shape[0]), int(x.shape[3]))
+            gi = None
+            if need_dx:
+                wz = torch.cat((weight.reshape(ci, co, 4, 4), weight.new_zeros(ci, co, 1, 4)), dim=2)
+                wz = torch.cat((wz, wz.new_zeros(ci, co, 5, 1)), dim=3)                        # [ci, co, 5, 5], index 4 = zero
+                wp = wz[:, :, tap[:, None, :, None], tap[None, :, None, :]]                    # [ci, co, pr, pc, ky', kx']
+                wp = wp.permute(0, 2, 3, 1, 4, 5).reshape(ci, 4 * co, 3, 3).contiguous()
+                gi = be.conv3x3_masked(P, ones, wp, be._const(dy.device, "zeros", ci))
             xm = be.add_masked(None, x, cols)
-            gi, gw, gb = torch.ops.aten.convolution_backward(dy, xm, weight, [ctx.bias_n], [2, 2], [1, 1], [1, 1], True, [0, 0], 1,
-                                                             [need_dx, True, True])
+            d6, _ = be.conv3x3_wgrad(P, ones, xm)                   # [ci][4 co][3][3]: "dy" role = x * mask, "x" role = the phases
+            d6 = d6.reshape(ci, 2, 2, co, 3, 3)
+            pr, kp = _up_tap_inverse(dy.device)                     # ky -> (phase, ky')
+            gw = d6[:, pr[:, None], pr[None, :], :, kp[:, None], kp[None, :]].permute(2, 3, 0, 1).contiguous()
+            gb = dy.sum((0, 2, 3))
         dx = be.add_masked(None, gi, cols) if need_dx else None
         return dx, None, gw, gb, None
+
+
+_UP_IDX = {}
+
+
+def _up_tap_index(device):
+    """[phase (0 odd rows, 1 even rows)][ky' of the 3x3 view] -> ky of the 4x4 kernel, 4 where the phase has no tap."""
+    key = (str(device), "fwd")
+    if key not in _UP_IDX:
+        _UP_IDX[key] = torch.tensor([[0, 2, 4], [4, 1, 3]], dtype=torch.long, device=device)
+    return _UP_IDX[key]
+
+
+def _up_tap_inverse(device):
+    """ky of the 4x4 kernel -> (phase, ky' of the 3x3 view)."""
+    key = (str(device), "inv")
+    if key not in _UP_IDX:
+        _UP_IDX[key] = (torch.tensor([0, 1, 0, 1], dtype=torch.long, device=device), torch.tensor([0, 1, 1, 2], dtype=torch.long, device=device))
+    return _UP_IDX[key]
 
 
 class ScoreLoss(torch.autograd.Function):
