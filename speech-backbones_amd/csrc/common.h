@@ -232,6 +232,9 @@ bool conv_ws_eligible(int mode, int c0, int c1, int cout, int pro, int epi, int 
 int conv_ws_nparts(int cout, int Hout, int Wout);      // GroupNorm partial slots per sample it writes (one per 32-frame x 5-row block)
 bool conv_ws_small(int cout, int groups, int Hout, int Wout, int B);   // the launch takes the three-wave workgroup form (same arithmetic)
 hipError_t launch_conv_ws(const ConvArgs &a, hipStream_t st);
+// conv_up.hip: Upsample with the four output phases computed from one staged tile (fp32 storage, bf16x3)
+bool conv_up4_eligible(const ConvArgs &a);
+hipError_t launch_conv_up4(const ConvArgs &a, hipStream_t st);
 bool conv_small_tiles(int mode, int cout, int Hout, int Wout, int B);   // half-height tiles for launches smaller than the chip
 bool conv_rowpair_stats(int mode, int cout, int Hout, int Wout);        // GroupNorm partial slots per row pair (batch-size independent)
 

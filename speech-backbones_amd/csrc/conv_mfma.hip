@@ -1017,6 +1017,7 @@ hipError_t launch_conv(int mode, const ConvArgs &a, hipStream_t st) {
                         : launch_prec<CONV_DN, 2, 2, 1, PRO_MASK, EPI_PLAIN>(a, st);
         case CONV_UP:
             if (a.pro != PRO_MASK || a.epi != EPI_PLAIN) break;
+            if (conv_up4_eligible(a)) return launch_conv_up4(a, st);
             return wide ? launch_prec<CONV_UP, 2, 2, 2, PRO_MASK, EPI_PLAIN>(a, st)
                         : launch_prec<CONV_UP, 1, 4, 2, PRO_MASK, EPI_PLAIN>(a, st);
         case CONV_P1:

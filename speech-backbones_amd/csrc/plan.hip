@@ -1381,6 +1381,7 @@ static std::string conv_kernel_name(int mode, int cin, int cout, int pro, int ep
                  abf ? "__bf16" : "float");
         return wb;
     }
+    if (mode == CONV_UP && nsplit == 2 && !abf && cin % 16 == 0 && pro == PRO_MASK && epi == EPI_PLAIN) return "gtts::conv_up4_kernel";   // conv_up.hip
     const int kch = conv_geom(mode, cin, cout).kch;
     const bool fullc = cin % 16 == 0;
     int wm, wn, mf;
