@@ -147,6 +147,8 @@ __global__ __launch_bounds__(256, 2) void conv_up4_kernel(const ConvArgs a) {
                 const bool last = st == 1 && j == 1;
                 const int nchk = last ? (chunk + 1 < nchunk ? chunk + 1 : chunk) : chunk;
                 wload(wn, nchk, last ? 0 : (j == 1 ? st + 1 : st), last ? 0 : (j == 1 ? 0 : 1));
+                __builtin_amdgcn_sched_barrier(0);      // (the requests stay in front of this tap's MFMAs: hipcc otherwise sinks
+                                                        // them below the last reader of the registers they overwrite)
                 bf16x8 xh[2][2], xl[2][2];      // [row][px]
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
