@@ -308,6 +308,9 @@ int gtts_gn_mish_backward(const float *dout, const float *y, const float *gamma,
  * x1 [B,cin-c0,H,W] (nullptr: one source, c0 ignored); c0 a multiple of 16 (forward) / 64 (weight gradient). */
 int gtts_conv3x3_masked2(const float *x, const float *x1, int c0, const float *mask, const void *packed, const float *bias, float *y,
                          int B, int cin, int cout, int H, int W, gtts_stream_t stream);
+/* the same with a column mask on the OUTPUT (omask [B][W], nullable): the data gradient of a masked convolution in one pass */
+int gtts_conv3x3_masked3(const float *x, const float *x1, int c0, const float *mask, const float *omask, const void *packed,
+                         const float *bias, float *y, int B, int cin, int cout, int H, int W, gtts_stream_t stream);
 int gtts_conv3x3_wgrad_tiled2(const float *x, const float *x1, int c0, const float *mask, const float *dy, float *dw, float *db,
                               void *workspace, size_t workspace_bytes, int B, int cin, int cout, int H, int W, gtts_stream_t stream);
 /* 1x1 convolutions (res_conv, to_qkv, to_out: diffusion.py:70,87-88): y = Conv2d_1x1(x * mask) + bias; the data gradient is the

@@ -101,6 +101,7 @@ def lib():
         L.gtts_conv1x1_wgrad_workspace_bytes.restype = sz
         L.gtts_conv1x1_wgrad.argtypes = [vp, vp, vp, vp, vp, vp, sz, i, i, i, i, i, vp]
         L.gtts_conv3x3_masked2.argtypes = [vp, vp, i, vp, vp, vp, vp, i, i, i, i, i, vp]
+        L.gtts_conv3x3_masked3.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, i, i, i, i, i, vp]
         L.gtts_conv3x3_wgrad_tiled2.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, sz, i, i, i, i, i, vp]
         L.gtts_conv_resample_packed_bytes.argtypes = [i, i, i]
         L.gtts_conv_resample_packed_bytes.restype = sz
@@ -918,7 +919,7 @@ def _const(device, kind, *shape):
     return v
 
 
-def _conv3x3_run(x, mask_cols, weight, bias, transposed, x1=None):
+def _conv3x3_run(x, mask_cols, weight, bias, transposed, x1=None, out_mask=None):
     B, c0, H, W = x.shape
     cin = c0 + (int(x1.shape[1]) if x1 is not None else 0)
     cout = weight.shape[1] if transposed else weight.shape[0]
@@ -926,8 +927,8 @@ def _conv3x3_run(x, mask_cols, weight, bias, transposed, x1=None):
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
     with _on(x.device):
         packed = _packed_conv3x3(weight, cin, cout, transposed)
-        _check(L.gtts_conv3x3_masked2(_ptr(x), _ptr(x1), c0, _ptr(mask_cols), _ptr(packed), _ptr(bias), _ptr(y), B, cin, cout, H, W,
-                                      _stream()), "gtts_conv3x3_masked")
+        _check(L.gtts_conv3x3_masked3(_ptr(x), _ptr(x1), c0, _ptr(mask_cols), _ptr(out_mask), _ptr(packed), _ptr(bias), _ptr(y), B, cin,
+                                      cout, H, W, _stream()), "gtts_conv3x3_masked")
     return y
 
 
@@ -938,11 +939,13 @@ def conv3x3_masked(x, mask_cols, weight, bias, x1=None):
     return _conv3x3_run(x, mask_cols, weight, bias, False, _f32c(x1, "x1"))
 
 
-def conv3x3_dgrad(dy, weight):
-    """Gradient of conv3x3_masked w.r.t. (x * mask): a 3x3 convolution of dy with the transposed, flipped weights."""
+def conv3x3_dgrad(dy, weight, mask_cols=None):
+    """Gradient of conv3x3_masked w.r.t. (x * mask): a 3x3 convolution of dy with the transposed, flipped weights; with
+    mask_cols [B,W] the gradient w.r.t. x itself (the mask is applied in the kernel's epilogue)."""
     dy, weight = _f32c(dy, "dy"), _f32c(weight, "weight")
     B, cout, H, W = dy.shape
-    return _conv3x3_run(dy, _const(dy.device, "ones", B, W), weight, _const(dy.device, "zeros", int(weight.shape[1])), True)
+    return _conv3x3_run(dy, _const(dy.device, "ones", B, W), weight, _const(dy.device, "zeros", int(weight.shape[1])), True,
+                        out_mask=_f32c(mask_cols, "mask"))
 
 
 def conv3x3_wgrad(x, mask_cols, dy, x1=None):

@@ -181,6 +181,8 @@ struct ConvArgs {
     const void *eres;       // EPI_ATTN: residual [B][cout][Hout][Wout]
     int nsplit;             // 2: bf16x3 (hi/lo), 1: plain bf16
     int use_ws;             // plan option gtts_unet_cfg.conv_ws: eligible Block convolutions take conv_ws.hip
+    const float *omask;     // EPI_PLAIN, conv_mfma.hip only: [B][Wout] column mask multiplied into the output (the data gradient
+                            // of a masked convolution, train.hip); nullptr: none
     int act_bf16;           // 1: activation tensors are stored as bf16 (GTTS_PREC_BF16_STORE)
     // EPI_STATS with the GroupNorm finalize fused in: the last workgroup of a sample to publish its partial sums (an
     // agent-scope ticket per sample) reduces them in a fixed order and writes the per-channel scale / shift.

@@ -683,6 +683,7 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
         if (pix_ok) {      // one exec-mask region per row; straight-line code inside
             float m_out = 0.f;
             if (EPI == EPI_TAIL) m_out = a.mask[(size_t)b * a.T + ((size_t)ox << a.lvl_out)];
+            if (EPI == EPI_PLAIN && a.omask) m_out = a.omask[(size_t)b * a.Wout + ox];
             const int voff = (oy * a.Wout + ox + 4 * kg_l * HWout) * AB;
 #pragma unroll
             for (int mi = 0; mi < MF; ++mi) {
@@ -703,6 +704,8 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
                         v += mish_f(y) * m_out;
                     } else if (EPI == EPI_ATTN) {
                         v += ex[rg];
+                    } else if (EPI == EPI_PLAIN) {
+                        if (a.omask) v *= m_out;
                     }
                     const int soff = (ch0 + mi * 32 + (rg & 3) + 8 * (rg >> 2)) * HWout * AB;
                     st_act<AT>(v, rs_out, voff, soff);

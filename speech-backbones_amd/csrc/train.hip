@@ -246,8 +246,10 @@ extern "C" int gtts_conv3x3_pack(const float *w, void *packed, int cin, int cout
 // y = Conv2d_3x3(x * mask, packed W) + bias; x [B,cin,H,W], mask [B,W] (columns), y [B,cout,H,W].  cout % 64 == 0 (128 above 64).
 // x1 (nullable) / c0: the input is the channel concatenation of x [B,c0,H,W] and x1 [B,cin-c0,H,W] (c0 a multiple of 16), read
 // in place (torch.cat of the up path, diffusion.py:166)
-extern "C" int gtts_conv3x3_masked2(const float *x, const float *x1, int c0, const float *mask, const void *packed, const float *bias,
-                                    float *y, int B, int cin, int cout, int H, int W, gtts_stream_t stream) {
+// omask (nullable): [B][W] column mask multiplied into the output -- the data gradient of a masked convolution is
+// conv(dy; transposed weights) * mask, and the mask rides in the epilogue instead of a second pass over dx
+extern "C" int gtts_conv3x3_masked3(const float *x, const float *x1, int c0, const float *mask, const float *omask, const void *packed,
+                                    const float *bias, float *y, int B, int cin, int cout, int H, int W, gtts_stream_t stream) {
     if (!x || !mask || !packed || !bias || !y) return tfail(GTTS_E_NULL, "gtts_conv3x3_masked: null argument");
     if (x1 && (c0 <= 0 || c0 >= cin || c0 % 16)) return tfail(GTTS_E_SHAPE, "gtts_conv3x3_masked: c0 must be a multiple of 16 inside (0, cin) (got %d of %d)", c0, cin);
     if (B <= 0 || cin <= 0 || cout <= 0 || H <= 0 || W <= 0) return tfail(GTTS_E_SHAPE, "gtts_conv3x3_masked: bad shape");
@@ -261,14 +263,20 @@ extern "C" int gtts_conv3x3_masked2(const float *x, const float *x1, int c0, con
     a.w = (const unsigned char *)packed; a.w_bstride = 0;
     a.bias = bias; a.bias_bstride = 0;
     a.cout = cout; a.out = y; a.groups = 8; a.nsplit = 2;
+    a.omask = omask;
     const hipError_t e = launch_conv(CONV_C3, a, (hipStream_t)stream);
     if (e != hipSuccess) return tfail(GTTS_E_HIP, "conv3x3 (cin %d, cout %d): %s", cin, cout, hipGetErrorString(e));
     return GTTS_OK;
 }
 
+extern "C" int gtts_conv3x3_masked2(const float *x, const float *x1, int c0, const float *mask, const void *packed, const float *bias,
+                                    float *y, int B, int cin, int cout, int H, int W, gtts_stream_t stream) {
+    return gtts_conv3x3_masked3(x, x1, c0, mask, nullptr, packed, bias, y, B, cin, cout, H, W, stream);
+}
+
 extern "C" int gtts_conv3x3_masked(const float *x, const float *mask, const void *packed, const float *bias, float *y, int B,
                                    int cin, int cout, int H, int W, gtts_stream_t stream) {
-    return gtts_conv3x3_masked2(x, nullptr, 0, mask, packed, bias, y, B, cin, cout, H, W, stream);
+    return gtts_conv3x3_masked3(x, nullptr, 0, mask, nullptr, packed, bias, y, B, cin, cout, H, W, stream);
 }
 
 // ---- 1x1 convolutions of the training path (res_conv, to_qkv, to_out: diffusion.py:70,87-88): forward and data gradient on

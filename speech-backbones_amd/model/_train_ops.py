@@ -39,11 +39,11 @@ class MaskedConv3x3(torch.autograd.Function):
         dx = dx1 = dw = db = None
         need1 = x1 is not None and ctx.needs_input_grad[4]
         if ctx.needs_input_grad[0] or need1:
-            full = be.conv3x3_dgrad(dy, weight)
             c0 = x.shape[1]
             if x1 is None:
-                dx = be.add_masked(None, full, cols)
+                dx = be.conv3x3_dgrad(dy, weight, cols)             # (the mask rides in the convolution's epilogue)
             else:                                                   # mask and split in one pass each (contiguous results)
+                full = be.conv3x3_dgrad(dy, weight)
                 if ctx.needs_input_grad[0]:
                     dx = be.add_masked(None, full, cols, channels=(0, c0))
                 if need1:
