@@ -73,6 +73,24 @@ def test_plan_layout_and_validation():
     assert S.Plan(keep_intermediates=True).workspace_bytes(2, 64) > S.Plan().workspace_bytes(2, 64)
 
 
+def test_conv_kernel_plan_option():
+    """gtts_unet_cfg.conv_ws (ABI 3): default by network width, never for the single-pass bf16 modes; the sub-batch stream
+    default follows it; the choice changes the GroupNorm partial-slot layout and therefore the workspace, never the weights."""
+    import copy
+    S = pkg()
+    grad, vc = S.Plan(), S.Plan(dim=256, arch=1)
+    assert grad.conv_ws is False and grad._nstreams == 3
+    assert vc.conv_ws is True and vc._nstreams == 2
+    forced = S.Plan(conv_ws=True)
+    assert forced.conv_ws is True and forced._nstreams == 2 and int(forced.cfg.conv_ws) == 1
+    assert S.Plan(conv_ws=True, precision=S.PREC_BF16_STORE).conv_ws is False
+    assert S.Plan(conv_ws=True, streams=3)._nstreams == 3
+    assert forced.packed_bytes() == grad.packed_bytes()
+    assert [k for k, _ in forced.param_layout()] == [k for k, _ in grad.param_layout()]
+    assert forced.workspace_bytes(2, 64) > 0 and grad.workspace_bytes(2, 64) > 0
+    assert copy.deepcopy(forced).conv_ws is True          # plans rebuild from their constructor arguments
+
+
 def test_no_cpu_fallback():
     import torch
     S = pkg()
