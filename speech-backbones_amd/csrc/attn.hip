@@ -40,6 +40,9 @@ __device__ __forceinline__ void pack8_split(const float (&v)[8], u32x4 &hi, u32x
 }
 
 // FULLC: C is a multiple of 32 (every staged channel exists)
+// (Measured and not kept, round 3: head PAIRS per workgroup -- the x tile loaded, split and staged once for two heads, each
+// head with its own projection accumulators / softmax state / context, records bit-identical.  128 + 32 accumulator registers
+// beside the 32-register x prefetch do not fit 256 VGPRs: 54 spilled registers, 81.6 vs 62.0 us per launch.)
 template <int NSPLIT, int FULLC, typename AT = float>
 __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
     constexpr int AB = (int)sizeof(AT);

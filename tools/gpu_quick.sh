@@ -1,10 +1,10 @@
 #!/bin/bash
-# quick sanity on one box visit: smoke, the Upsample-touching parity tests, two bench repeats with the per-kernel table
+# quick sanity on one box visit: smoke, the per-op / golden parity tests, two bench repeats with the per-kernel table
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout 200 python __graft_entry__.py --smoke 2>&1 | tail -1
-timeout 300 python -m pytest tests/test_gpu_parity_full.py tests/test_gpu_training.py -m gpu -q -x -p no:cacheprovider -k "taps or resample or golden" 2>&1 | tail -2
+timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_parity_full.py -m gpu -q -x -p no:cacheprovider -k "taps or golden or batch_size" 2>&1 | tail -2
 for rep in 1 2; do
 timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/q_bench_$rep.json 2> gpurun_out/q_tables_$rep.txt
 echo "bench: $(python -c "import json;d=json.load(open('gpurun_out/q_bench_$rep.json'));print(d['value'], d['config'].get('ms_per_unet_call'))")"
 done
-grep -E "conv_up4" gpurun_out/q_tables_1.txt
+grep -E "attn_ctx" gpurun_out/q_tables_1.txt
