@@ -19,13 +19,13 @@ __global__ __launch_bounds__(256) void add_masked_kernel(const float *__restrict
                                                          float *__restrict__ out, int C, int HW, int W, size_t b_bstride) {
     const int bc = blockIdx.x, bi = bc / C;
     const size_t base = (size_t)bc * HW;
-    b += (size_t)bi * b_bstride + (size_t)(bc - bi * C) * HW - base;      // (b[base + i] below lands in the slice)
+    const float *bp = b + (size_t)bi * b_bstride + (size_t)(bc - bi * C) * HW;      // this (sample, channel) plane of the slice
     const float *mrow = mask ? mask + (size_t)bi * W : nullptr;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i = blockIdx.y * 1024 + k * 256 + threadIdx.x;
         if (i < HW) {
-            const float bv = mrow ? b[base + i] * mrow[i % W] : b[base + i];
+            const float bv = mrow ? bp[i] * mrow[i % W] : bp[i];
             out[base + i] = a ? a[base + i] + bv : bv;
         }
     }
