@@ -156,3 +156,30 @@ def test_mas_cpu_twin_bit_exact():
         assert torch.equal(got, MAS.maximum_path_port(value, mask))
         if MAS.ref_available():
             assert torch.equal(got, MAS.maximum_path_ref(value, mask))
+
+
+def test_oracle_is_test_infrastructure_only():
+    """Nothing under the package imports oracle/; bench.py touches it only inside its CPU-baseline legs (the functions whose
+    result is a `cpu_baseline` / `cpu_ms` entry), never for weights, inputs or the measured path."""
+    import ast
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg_dir = os.path.join(root, "speech-backbones_amd")
+    for dirpath, _, files in os.walk(pkg_dir):
+        for fn in files:
+            if fn.endswith(".py"):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert "from oracle" not in src and "import oracle" not in src, os.path.join(dirpath, fn)
+    tree = ast.parse(open(os.path.join(root, "bench.py")).read())
+    allowed = {"cpu_baseline", "cpu_baseline_vc", "bench_hifigan", "mas"}
+
+    def walk(node, fn_stack):
+        if isinstance(node, (ast.FunctionDef, ast.AsyncFunctionDef)):
+            fn_stack = fn_stack + [node.name]
+        if isinstance(node, ast.ImportFrom) and (node.module or "").split(".")[0] == "oracle":
+            assert fn_stack and fn_stack[-1] in allowed, "bench.py imports oracle in %s" % (fn_stack or ["<module>"])
+        if isinstance(node, ast.Import):
+            assert all(a.name.split(".")[0] != "oracle" for a in node.names)
+        for ch in ast.iter_child_nodes(node):
+            walk(ch, fn_stack)
+    walk(tree, [])
