@@ -153,3 +153,19 @@ def test_parameter_gradients_match_reference_loss_t(n_spks):
         scale = float(g.abs().max()) + 1e-12
         assert float((p.grad - g).abs().max()) <= 2e-5 * scale + 1e-9, (name, float((p.grad - g).abs().max()), scale)
     assert n >= 172
+
+
+@pytest.mark.parametrize("tag,n_spks", [("s1", 1), ("s3", 3)])
+def test_loss_and_gradients_match_reference_golden(tag, n_spks):
+    """The same comparison without /root/reference (what travels to the GPU box): tests/golden/loss_grads.npz holds the
+    reference's loss, noised sample and, per parameter, gradient norm / max / 16 entries (make_golden_grads.py)."""
+    import numpy as np
+    import os
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loss_grads.npz"))
+    D = importlib.import_module("speech-backbones_amd.model.diffusion")
+    sd = O.make_estimator_state(n_spks=n_spks, seed=int(G[tag + "_seed"]))
+    assert abs(sum(float(v.double().abs().sum()) for v in sd.values()) - float(G[tag + "_checksum"])) <= 1e-6 * float(G[tag + "_checksum"])
+    dec = D.Diffusion(80, 64, n_spks, 64, 0.05, 20.0, 1000)
+    dec.estimator.load_state_dict(sd, strict=True)
+    from helpers_golden import check_against_golden_grads
+    check_against_golden_grads(dec, G, tag, torch.device("cpu"), 2e-5)
