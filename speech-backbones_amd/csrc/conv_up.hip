@@ -15,6 +15,9 @@
 // are bit-identical to the per-phase form.  Weight fragments come straight from the fragment-ordered blob (16-byte buffer
 // loads, one tap ahead); the next chunk's activation loads are in flight across the MFMAs; one barrier per chunk (two LDS
 // images).  fp32 storage, bf16x3 only (the single-pass bf16 modes keep the per-phase kernel).
+// Measured (B = 16, both layers): 130-135 us avg against 148 for the per-phase form.  At bf16x3 the 64-channel layer executes
+// 129 GFLOP (52 us at peak, ~100 us at the 0.5 of peak this chip sustains under MFMA load), so the remaining gap is MFMA
+// time and the epilogue's 1024 lines per tile, not HBM.
 #include "common.h"
 #include "kernels.h"
 #include <atomic>
