@@ -262,8 +262,8 @@ int gtts_postnet_forward(const gtts_postnet *pn, const void *packed, const float
                          void *workspace, size_t workspace_bytes, int B, int T, gtts_stream_t stream);
 
 /* ---- training hot path, first kernels (Grad-TTS/train.py:105-119; Grad-TTS/model/diffusion.py:244-252,281-294) --------
- * The host (model/_train_ops.py) wraps these in torch.autograd.Function; everything else of the backward pass is still
- * PyTorch autograd. */
+ * The host (model/_train_ops.py) wraps these and the ABI-3 entry points further down in torch.autograd.Function; autograd only
+ * sequences them (and adds gradient accumulations). */
 /* Diffusion.forward_diffusion: xt = (x0 d + mu (1-d) + z sqrt(1 - e^{-cum})) mask, z_masked = z mask; d = e^{-cum/2},
  * cum = beta_min t + (beta_max - beta_min) t^2 / 2 per sample; x0, mu, z, xt, z_masked [B,F,T], mask [B,T], t [B]. */
 int gtts_diffusion_noising(const float *x0, const float *mu, const float *z, const float *mask, const float *t, float beta_min,
@@ -303,7 +303,8 @@ int gtts_gn_mish_backward(const float *dout, const float *y, const float *gamma,
                           int groups, gtts_stream_t stream);
 
 /* ---- training hot path, the rest of the score network (ABI 3; Grad-TTS/model/diffusion.py:19-108,140-176) ----------------
- * Every tensor-sized op of Diffusion.compute_loss's forward and backward except Upsample's gradients (MIOpen). */
+ * Every tensor-sized op of Diffusion.compute_loss's forward and backward (Upsample's gradients run as stride-1 3x3 operations
+ * over gtts_space_to_depth2 planes: no MIOpen / rocBLAS kernel is left in the step). */
 /* Block's convolution on a channel concatenation read in place (torch.cat of the up path, diffusion.py:166): x [B,c0,H,W],
  * x1 [B,cin-c0,H,W] (nullptr: one source, c0 ignored); c0 a multiple of 16 (forward) / 64 (weight gradient). */
 int gtts_conv3x3_masked2(const float *x, const float *x1, int c0, const float *mask, const void *packed, const float *bias, float *y,
@@ -391,6 +392,17 @@ int gtts_profile_enable(gtts_plan *plan, int on);
 /* Synchronises the recorded events, adds elapsed milliseconds and launch counts per op into the two arrays
  * (length gtts_plan_num_ops) and clears the record. */
 int gtts_profile_collect(gtts_plan *plan, double *ms_per_op, long long *launches_per_op);
+
+/* ---- measurement: ceilings of THIS chip, measured (SURVEY.md section 8d "a measured hipMemcpy/stream-triad ceiling") ----
+ * Both enqueue ONE kernel on `stream`; the caller times it (HIP events) and divides.  Nothing on the sampling path calls them.
+ * gtts_ubench_mfma: `workgroups` x 4 waves each issue iters x 8 independent v_mfma_f32_32x32x16_bf16 whose operand fragments
+ *   are read from src (>= 4096 bytes of bf16 data: pass random values -- the chip clocks to its power budget and all-zero
+ *   operands overstate what live data reaches); out: gtts_ubench_mfma_out_floats(workgroups) floats; *flops = FLOPs enqueued.
+ * gtts_ubench_hbm: mode 0 c = a (8 bytes per element), 1 c = a + 1.5 b (12), 2 read-only sweep of a (4); n floats, a multiple
+ *   of 4, buffers 16-byte aligned; *bytes = bytes the launch moves. */
+size_t gtts_ubench_mfma_out_floats(int workgroups);
+int gtts_ubench_mfma(const void *src, size_t src_bytes, float *out, int workgroups, int iters, double *flops, gtts_stream_t stream);
+int gtts_ubench_hbm(const float *a, const float *b, float *c, size_t n, int mode, int workgroups, double *bytes, gtts_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -181,6 +181,10 @@ def lib():
                                         ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         L.gtts_profile_enable.argtypes = [vp, i]
         L.gtts_profile_collect.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]
+        L.gtts_ubench_mfma_out_floats.argtypes = [i]
+        L.gtts_ubench_mfma_out_floats.restype = sz
+        L.gtts_ubench_mfma.argtypes = [vp, sz, vp, i, i, ctypes.POINTER(ctypes.c_double), vp]
+        L.gtts_ubench_hbm.argtypes = [vp, vp, vp, sz, i, i, ctypes.POINTER(ctypes.c_double), vp]
         if L.gtts_abi_version() != 3:
             raise RuntimeError("libgradtts_gfx950.so ABI version mismatch")
         _lib = L
@@ -863,18 +867,46 @@ def mas_maximum_path(value, mask):
 
 
 # ---- training hot path (csrc/train.hip): raw kernels; the autograd wiring lives in model/_train_ops.py
-def conv3x3_supported(cin, cout, need_dgrad=True):
-    """Channel counts the training conv kernels take (forward / data gradient / weight gradient).  The first layer (the stacked
-    2- or 3-plane input, no data gradient wanted) has its own weight-gradient kernel."""
+_MAX_TENSOR_ELEMS = 1 << 29      # per call: B * max(cin, cout) * H * W (32-bit byte offsets inside the kernels; train_wgrad.hip)
+
+
+def conv_size_ok(B, cin, cout, H, W):
+    """The training kernels address one call's tensors with 32-bit byte offsets: larger shapes must take the torch path."""
+    return int(B) * max(int(cin), int(cout)) * int(H) * int(W) < _MAX_TENSOR_ELEMS
+
+
+def conv3x3_supported(cin, cout, need_dgrad=True, shape=None):
+    """Channel counts (and, with shape = (B, H, W), tensor sizes) the training conv kernels take (forward / data gradient /
+    weight gradient).  The first layer (the stacked 2- or 3-plane input, no data gradient wanted) has its own weight-gradient
+    kernel."""
     def tiles(c):
         return c == 64 or (c > 64 and c % 128 == 0)
+    if shape is not None and not conv_size_ok(shape[0], cin, cout, shape[1], shape[2]):
+        return False
     if cin in (2, 3) and not need_dgrad:
         return tiles(cout)
     return cin % 32 == 0 and cout % 32 == 0 and tiles(cin) and tiles(cout)
 
 
-_PACKED = {}       # (id(weight), transposed, kind) -> (weakref to the weight, its version, packed blob)
+_PACKED = {}       # (id(weight), transposed, kind) -> (weakref to the weight, its version, pack generation, packed blob)
+_PACK_GEN = 0      # a packed copy is shared only by the forward and the backward of ONE estimator call (new_pack_generation)
 _CONSTS = {}       # (device, kind, n) -> ones / zeros of the data-gradient call
+
+
+def new_pack_generation():
+    """Called at every entry of the training estimator (model/_train_ops.py): packed weight copies made before this point are
+    not reused.  Tensor._version does not see writes through `p.data` (EMA swaps, manual SGD, `p.data = t`); with the generation
+    in the validity check a stale pack cannot outlive the step that made it, at the price of one re-pack (microseconds) per
+    convolution and step."""
+    global _PACK_GEN
+    _PACK_GEN += 1
+
+
+def clear_packed_cache():
+    """Drop every cached packed training weight (Diffusion.invalidate_packed and the load_state_dict hook call this)."""
+    global _PACK_GEN
+    _PACK_GEN += 1
+    _PACKED.clear()
 
 
 def _packed_weight(weight, cin, cout, transposed, kind):
@@ -883,8 +915,9 @@ def _packed_weight(weight, cin, cout, transposed, kind):
     alone can be recycled by the caching allocator for a different weight of the same shape)."""
     key = (id(weight), bool(transposed), kind)
     hit = _PACKED.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == int(weight._version) and hit[2].device == weight.device:
-        return hit[2]
+    if (hit is not None and hit[0]() is weight and hit[1] == int(weight._version) and hit[2] == _PACK_GEN and
+            hit[3].device == weight.device):
+        return hit[3]
     L = lib()
     if kind in ("3x3", "1x1"):
         nbytes, pack = ((L.gtts_conv3x3_packed_bytes, L.gtts_conv3x3_pack) if kind == "3x3" else (L.gtts_conv1x1_packed_bytes, L.gtts_conv1x1_pack))
@@ -902,7 +935,7 @@ def _packed_weight(weight, cin, cout, transposed, kind):
             del _PACKED[k]
         if len(_PACKED) >= 512:
             _PACKED.clear()
-    _PACKED[key] = (weakref.ref(weight), int(weight._version), packed)
+    _PACKED[key] = (weakref.ref(weight), int(weight._version), _PACK_GEN, packed)
     return packed
 
 
@@ -972,11 +1005,13 @@ def conv3x3_wgrad(x, mask_cols, dy, x1=None):
     return dw, db
 
 
-def conv1x1_supported(cin, cout, need_dgrad=True):
-    """Channel counts the 1x1 training kernels take: forward cout (and, for the data gradient, cin) a whole number of the
-    kernel's output tiles; the weight gradient whole 64 x 64 tiles."""
+def conv1x1_supported(cin, cout, need_dgrad=True, shape=None):
+    """Channel counts (and, with shape = (B, H, W), tensor sizes) the 1x1 training kernels take: forward cout (and, for the
+    data gradient, cin) a whole number of the kernel's output tiles; the weight gradient whole 64 x 64 tiles."""
     def tiles(c):
         return c == 64 or (c > 64 and c % 128 == 0)
+    if shape is not None and not conv_size_ok(shape[0], cin, cout, shape[1], shape[2]):
+        return False
     if cin in (2, 3) and not need_dgrad:          # first layer: own weight-gradient kernel
         return tiles(cout)
     return tiles(cout) and cin % 64 == 0 and (tiles(cin) or not need_dgrad)
@@ -1103,9 +1138,12 @@ def final_conv_backward(x, weight, mask_cols, dout):
     return dx, dw, db
 
 
-def resample_supported(cin, cout, H, W, up):
+def resample_supported(cin, cout, H, W, up, B=1):
     def tiles(c):
         return c == 64 or (c > 64 and c % 128 == 0)
+    # largest tensor of the call and of its gradients: Upsample's output (and its space_to_depth planes) is 4 cout planes of H x W
+    if not conv_size_ok(B, 4 * max(cin, cout) if up else max(cin, cout), 1, H, W):
+        return False
     return tiles(cin) and tiles(cout) and (up or (H % 2 == 0 and W % 2 == 0))
 
 
@@ -1277,3 +1315,52 @@ def expand_alignment(duration, x_mask, y_lengths, mu_x, T, noise=None, temperatu
         _check(lib().gtts_expand_alignment(_ptr(d), _ptr(m), _ptr(yl), _ptr(mx), _ptr(nz), float(temperature), _ptr(attn),
                                            _ptr(mu_y), _ptr(z), B, F, tx, int(T), _stream()), "gtts_expand_alignment")
     return attn, mu_y, z
+
+
+def measured_ceilings(device, seconds=2.0):
+    """Measured ceilings of this chip (bench.py roofline): bf16 MFMA TFLOP/s on random / zero operands and HBM GB/s for a
+    16-byte copy, triad and read-only sweep.  About `seconds` of GPU time in total.  Returns a dict."""
+    L = lib()
+    out = {}
+    with _on(device):
+        st = _stream()
+        props = torch.cuda.get_device_properties(device)
+        cus = int(props.multi_processor_count)
+        wgs = cus * 2                                   # 2 workgroups x 4 waves per CU = 2 waves per SIMD
+        g = torch.Generator(device="cpu").manual_seed(0)
+        rnd = torch.randn(1 << 20, generator=g).to(torch.bfloat16).to(device)
+        zero = torch.zeros(1 << 20, dtype=torch.bfloat16, device=device)
+        sink = torch.empty(int(L.gtts_ubench_mfma_out_floats(wgs)), dtype=torch.float32, device=device)
+        flops = ctypes.c_double(0.0)
+
+        def timed(fn, reps):
+            fn()
+            torch.cuda.synchronize(device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) * 1e-3 / reps
+
+        iters = 4000                                    # 32 k MFMAs per wave: ~0.55 ms per launch at peak
+        for name, src in (("random", rnd), ("zero", zero)):
+            fn = lambda: _check(L.gtts_ubench_mfma(_ptr(src), ctypes.c_size_t(src.numel() * 2), _ptr(sink), wgs, iters,
+                                                   ctypes.byref(flops), st), "gtts_ubench_mfma")
+            t1 = timed(fn, 3)
+            reps = max(3, int(seconds * 0.3 / max(t1, 1e-6)))      # long enough for the clock to settle at its power budget
+            t = timed(fn, reps)
+            out["mfma_bf16_tflops_%s" % name] = flops.value / t * 1e-12
+        n = 1 << 28                                     # 1 GiB per buffer: four times the Infinity Cache
+        a = torch.empty(n, dtype=torch.float32, device=device).normal_()
+        b = torch.empty(n, dtype=torch.float32, device=device).normal_()
+        c = torch.empty(n, dtype=torch.float32, device=device)
+        nbytes = ctypes.c_double(0.0)
+        for name, mode in (("copy", 0), ("triad", 1), ("read", 2)):
+            fn = lambda: _check(L.gtts_ubench_hbm(_ptr(a), _ptr(b), _ptr(c), ctypes.c_size_t(n), mode, cus * 16,
+                                                  ctypes.byref(nbytes), st), "gtts_ubench_hbm")
+            t = timed(fn, 5)
+            out["hbm_%s_gbs" % name] = nbytes.value / t * 1e-9
+        out["cus"] = cus
+    return out

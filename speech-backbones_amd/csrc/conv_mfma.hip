@@ -54,6 +54,12 @@
 #ifndef GTTS_LDS_MIN
 #define GTTS_LDS_MIN 0
 #endif
+// GTTS_C3_LDS_MIN (any build): minimum dynamic LDS bytes of the bf16x3 Block convolutions (3x3, GroupNorm statistics
+// epilogue) only -- caps how many of THEM a CU holds (> 54 KB: two) while leaving its registers and wave slots to the
+// bandwidth-bound kernels of the other sub-batch streams.  0 = off.
+#ifndef GTTS_C3_LDS_MIN
+#define GTTS_C3_LDS_MIN 0
+#endif
 #ifndef GTTS_EXP
 #define GTTS_EXP 0
 #endif
@@ -908,6 +914,7 @@ static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
                   (ConvWdma<MODE, WM, FULLC>::on ? (size_t)C::WBLK16 * 16 : 0) +
                   (ConvAdbuf<MODE, WM, FULLC>::on ? (size_t)C::NPIX * C::NKG * 16 * 2 : 0);
     if (smem < (size_t)GTTS_LDS_MIN) smem = (size_t)GTTS_LDS_MIN;
+    if (MODE == CONV_C3 && NSPLIT == 2 && (EPI == EPI_STATS || EPI == EPI_PLAIN) && smem < (size_t)GTTS_C3_LDS_MIN) smem = (size_t)GTTS_C3_LDS_MIN;
     // hipFuncSetAttribute is per device: remember the largest size set on each device (atomics: launches may come
     // from several host threads; setting the attribute twice is harmless)
     static std::atomic<size_t> attr_set[64];

@@ -254,14 +254,18 @@ FORCE_TORCH = False      # measurement switch (bench.py train_step): route every
 
 
 def _hip_conv_ok(v, conv):
+    # (shape: the kernels address one call's tensors with 32-bit byte offsets -- oversize batches / crops take the torch path
+    # up front instead of failing inside loss.backward())
     return (not FORCE_TORCH and v.is_cuda and v.dtype == torch.float32 and conv.kernel_size == (3, 3) and
-            backend().conv3x3_supported(conv.in_channels, conv.out_channels, need_dgrad=v.requires_grad))
+            backend().conv3x3_supported(conv.in_channels, conv.out_channels, need_dgrad=v.requires_grad,
+                                        shape=(v.shape[0], v.shape[2], v.shape[3])))
 
 
 def _conv1x1(v, m, conv):
     """conv(v * m) for a 1x1 nn.Conv2d (m None: no mask)."""
     if (not FORCE_TORCH and v.is_cuda and v.dtype == torch.float32 and conv.kernel_size == (1, 1) and
-            backend().conv1x1_supported(conv.in_channels, conv.out_channels, need_dgrad=v.requires_grad)):
+            backend().conv1x1_supported(conv.in_channels, conv.out_channels, need_dgrad=v.requires_grad,
+                                        shape=(v.shape[0], v.shape[2], v.shape[3]))):
         return MaskedConv1x1.apply(v.contiguous(), m, conv.weight, conv.bias)
     return F.conv2d(v if m is None else v * m, conv.weight, conv.bias)
 
@@ -327,7 +331,7 @@ def resnet(rb, v, m, temb, v1=None, tb=None):
 
 
 def _resample(v, m, conv, up):
-    if _hip(v) and backend().resample_supported(v.shape[1], conv.out_channels, v.shape[2], v.shape[3], up):
+    if _hip(v) and backend().resample_supported(v.shape[1], conv.out_channels, v.shape[2], v.shape[3], up, B=v.shape[0]):
         return ResampleConv.apply(v.contiguous(), m, conv.weight, conv.bias, up)
     return conv(v * m)
 
@@ -363,6 +367,8 @@ def time_embedding(est, t):
 
 
 def estimator(est, x, mask, mu, t, spk=None):
+    if not FORCE_TORCH and x.is_cuda:
+        backend().new_pack_generation()        # packed weight copies live for this call's forward + backward only
     temb = time_embedding(est, t)
     planes = [mu, x]
     if est.n_spks >= 2:

@@ -205,6 +205,7 @@ class GradLogPEstimator2d(BaseModule):
         `p.data.mul_()`, as EMA weight swaps do): those do not bump `_version`.  Call this after such an edit."""
         self._hip_blob = None
         self._hip_key = None
+        backend().clear_packed_cache()          # the training kernels' packed copies (keyed on version + generation)
 
     def _plan(self):
         if tuple(self.dim_mults) != (1, 2, 4) or self.groups != 8:
