@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GTTS_ABI_VERSION 3
+#define GTTS_ABI_VERSION 4
 
 enum {
     GTTS_OK = 0,
@@ -392,14 +392,19 @@ int gtts_profile_enable(gtts_plan *plan, int on);
 /* Synchronises the recorded events, adds elapsed milliseconds and launch counts per op into the two arrays
  * (length gtts_plan_num_ops) and clears the record. */
 int gtts_profile_collect(gtts_plan *plan, double *ms_per_op, long long *launches_per_op);
+/* ABI 4: gtts_profile_enable(plan, 2) keeps the sub-batch streams ON and brackets every launch with events on ITS stream;
+ * gtts_profile_timeline then returns, per launch (at most cap), the op index, the stream (0: the call's stream, 1 + h: side
+ * stream h) and start / end in milliseconds relative to the first recorded launch (HIP event timestamps share one clock
+ * across streams): an un-traced timeline of which kernels were in flight together.  Clears the record. */
+int gtts_profile_timeline(gtts_plan *plan, int cap, int *op, int *stream, double *t0_ms, double *t1_ms, int *n);
 
 /* ---- measurement: ceilings of THIS chip, measured (SURVEY.md section 8d "a measured hipMemcpy/stream-triad ceiling") ----
  * Both enqueue ONE kernel on `stream`; the caller times it (HIP events) and divides.  Nothing on the sampling path calls them.
  * gtts_ubench_mfma: `workgroups` x 4 waves each issue iters x 8 independent v_mfma_f32_32x32x16_bf16 whose operand fragments
  *   are read from src (>= 4096 bytes of bf16 data: pass random values -- the chip clocks to its power budget and all-zero
  *   operands overstate what live data reaches); out: gtts_ubench_mfma_out_floats(workgroups) floats; *flops = FLOPs enqueued.
- * gtts_ubench_hbm: mode 0 c = a (8 bytes per element), 1 c = a + 1.5 b (12), 2 read-only sweep of a (4); n floats, a multiple
- *   of 4, buffers 16-byte aligned; *bytes = bytes the launch moves. */
+ * gtts_ubench_hbm: mode 0 c = a (8 bytes per element), 1 c = a + 1.5 b (12), 2 read-only sweep of a (4), + 4: the same with
+ *   nontemporal loads / stores; n floats, a multiple of 4, buffers 16-byte aligned; *bytes = bytes the launch moves. */
 size_t gtts_ubench_mfma_out_floats(int workgroups);
 int gtts_ubench_mfma(const void *src, size_t src_bytes, float *out, int workgroups, int iters, double *flops, gtts_stream_t stream);
 int gtts_ubench_hbm(const float *a, const float *b, float *c, size_t n, int mode, int workgroups, double *bytes, gtts_stream_t stream);

@@ -181,11 +181,13 @@ def lib():
                                         ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         L.gtts_profile_enable.argtypes = [vp, i]
         L.gtts_profile_collect.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]
+        L.gtts_profile_timeline.argtypes = [vp, i, ctypes.POINTER(i), ctypes.POINTER(i), ctypes.POINTER(ctypes.c_double),
+                                            ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i)]
         L.gtts_ubench_mfma_out_floats.argtypes = [i]
         L.gtts_ubench_mfma_out_floats.restype = sz
         L.gtts_ubench_mfma.argtypes = [vp, sz, vp, i, i, ctypes.POINTER(ctypes.c_double), vp]
         L.gtts_ubench_hbm.argtypes = [vp, vp, vp, sz, i, i, ctypes.POINTER(ctypes.c_double), vp]
-        if L.gtts_abi_version() != 3:
+        if L.gtts_abi_version() != 4:
             raise RuntimeError("libgradtts_gfx950.so ABI version mismatch")
         _lib = L
         return _lib
@@ -518,7 +520,17 @@ class Plan:
         return out
 
     def profile(self, on):
-        _check(lib().gtts_profile_enable(self._h, 1 if on else 0), "gtts_profile_enable")
+        """on = True / 1: per-op durations (the sampler runs unsplit); on = 2: timeline mode (sub-batch streams stay on, see
+        profile_timeline); False / 0: off."""
+        _check(lib().gtts_profile_enable(self._h, 2 if on == 2 else (1 if on else 0)), "gtts_profile_enable")
+
+    def profile_timeline(self, cap=1 << 18):
+        """[(op index, stream index, start ms, end ms)] of every launch recorded in timeline mode; clears the record."""
+        op, st = (ctypes.c_int * cap)(), (ctypes.c_int * cap)()
+        t0, t1 = (ctypes.c_double * cap)(), (ctypes.c_double * cap)()
+        n = ctypes.c_int(0)
+        _check(lib().gtts_profile_timeline(self._h, cap, op, st, t0, t1, ctypes.byref(n)), "gtts_profile_timeline")
+        return [(op[k], st[k], t0[k], t1[k]) for k in range(n.value)]
 
     def profile_collect(self):
         """(ms per op, launches per op) accumulated since profiling was enabled; clears the record."""
@@ -1352,15 +1364,29 @@ def measured_ceilings(device, seconds=2.0):
             reps = max(3, int(seconds * 0.3 / max(t1, 1e-6)))      # long enough for the clock to settle at its power budget
             t = timed(fn, reps)
             out["mfma_bf16_tflops_%s" % name] = flops.value / t * 1e-12
+        # what the vendor's GEMM library reaches on the same chip with the same kind of data (hipBLASLt through torch.matmul,
+        # 8192^3 bf16): the practical ceiling of an LDS-fed MFMA kernel, beside the register-only stream above
+        m = 8192
+        ga = torch.randn(m, m, generator=g).to(torch.bfloat16).to(device)
+        gb = torch.randn(m, m, generator=g).to(torch.bfloat16).to(device)
+        t = timed(lambda: torch.matmul(ga, gb), 10)
+        out["gemm_bf16_tflops_random_hipblaslt"] = 2.0 * m ** 3 / t * 1e-12
+        del ga, gb
         n = 1 << 28                                     # 1 GiB per buffer: four times the Infinity Cache
         a = torch.empty(n, dtype=torch.float32, device=device).normal_()
         b = torch.empty(n, dtype=torch.float32, device=device).normal_()
         c = torch.empty(n, dtype=torch.float32, device=device)
         nbytes = ctypes.c_double(0.0)
         for name, mode in (("copy", 0), ("triad", 1), ("read", 2)):
-            fn = lambda: _check(L.gtts_ubench_hbm(_ptr(a), _ptr(b), _ptr(c), ctypes.c_size_t(n), mode, cus * 16,
-                                                  ctypes.byref(nbytes), st), "gtts_ubench_hbm")
-            t = timed(fn, 5)
-            out["hbm_%s_gbs" % name] = nbytes.value / t * 1e-9
+            best = 0.0
+            for nt in (0, 4):                           # plain and nontemporal accesses, a few grid sizes: keep the best
+                for wpc in (4, 8, 16):
+                    fn = lambda: _check(L.gtts_ubench_hbm(_ptr(a), _ptr(b), _ptr(c), ctypes.c_size_t(n), mode + nt, cus * wpc,
+                                                          ctypes.byref(nbytes), st), "gtts_ubench_hbm")
+                    t = timed(fn, 3)
+                    gbs = nbytes.value / t * 1e-9
+                    out.setdefault("hbm_detail", {})["%s_%s_wg%d" % (name, "nt" if nt else "plain", wpc)] = round(gbs, 1)
+                    best = max(best, gbs)
+            out["hbm_%s_gbs" % name] = best
         out["cus"] = cus
     return out

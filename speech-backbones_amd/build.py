@@ -54,5 +54,41 @@ def build(force=False, verbose=False):
     return LIB
 
 
+# Reference variant for the GPU test suite: the fused GroupNorm finalize with the textbook agent-scope release / acquire fences
+# (common.h, GTTS_FENCED_FINALIZE).  Only the two files that contain the hand-off are recompiled; everything else links from the
+# product's objects.  tests/test_gpu_fenced.py compares the two libraries bit for bit.
+FENCED_LIB = os.path.join(HERE, "libgtts_fenced.so")
+FENCED_SOURCES = ["conv_mfma.hip", "conv_ws.hip"]
+
+
+def build_fenced(force=False):
+    product = build()
+    deps = [os.path.join(CSRC, f) for f in FENCED_SOURCES + HEADERS] + [product, os.path.abspath(__file__)]
+    if not force and os.path.exists(FENCED_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(FENCED_LIB) for d in deps):
+        return FENCED_LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    pdir = os.path.join(HERE, "build", os.path.basename(product).replace(".so", ""))
+    fdir = os.path.join(HERE, "build", "libgtts_fenced")
+    os.makedirs(fdir, exist_ok=True)
+    procs, objs = [], []
+    for src in SOURCES:
+        if src not in FENCED_SOURCES:
+            objs.append(os.path.join(pdir, src.replace(".hip", ".o")))
+            continue
+        obj = os.path.join(fdir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-DGTTS_FENCED_FINALIZE=1"]
+        cmd += PER_FILE_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            sys.stderr.write(out.decode())
+            raise RuntimeError("hipcc failed on %s (fenced variant)" % src)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", FENCED_LIB] + objs)
+    return FENCED_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_fenced(force="--force" in sys.argv))

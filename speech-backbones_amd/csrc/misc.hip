@@ -177,45 +177,106 @@ __device__ __forceinline__ void st4(__bf16 *p, float4 v) {
     *reinterpret_cast<bf16x4 *>(p) = o;
 }
 
-template <int VEC, typename AT>
-__global__ void tail_identity_kernel(const AT *__restrict__ h, const AT *__restrict__ x,
+// ITEMS (VEC-wide) items per thread, one block-stride apart; all loads of a thread are issued before the first use.
+// Measured (round 4): neither 16-byte bf16 accesses nor four items per thread (a quarter of the workgroups) move this kernel --
+// 64-72 us per launch in fp32 AND in bf16 storage (5.3 vs 2.9 TB/s): at two transcendentals + ~12 VALU per element Mish itself
+// is ~45 us of issue time at level 0, so the bf16 form is VALU-bound, the fp32 form HBM-bound, at about the same time.
+template <int VEC, typename AT, int ITEMS>
+__global__ __launch_bounds__(256) void tail_identity_kernel(const AT *__restrict__ h, const AT *__restrict__ x,
                                      const float *__restrict__ sc, const float *__restrict__ sh,
                                      const float *__restrict__ mask, AT *__restrict__ out, int C, int H, int W,
                                      int T, int lvl) {
-    // grid: (ceil(H*W/VEC/256), C, B): one (sample, channel) plane per blockIdx.(y,z) -> scalar scale/shift
+    // grid: (ceil(H*W/VEC/256/ITEMS), C, B): one (sample, channel) plane per blockIdx.(y,z) -> scalar scale/shift
     const int b = blockIdx.z, c = blockIdx.y;
-    const int i = (blockIdx.x * 256 + threadIdx.x) * VEC;
-    if (i >= H * W) return;
+    const int HW = H * W;
+    const int i0 = (blockIdx.x * ITEMS * 256 + threadIdx.x) * VEC;
+    if (i0 >= HW) return;
     const float a = sc[(size_t)b * C + c], s = sh[(size_t)b * C + c];
-    const size_t base = ((size_t)b * C + c) * H * W + i;
-    const int col = i % W;
-    if (VEC == 4) {
-        const float4 hv = ld4(h + base);
-        const float4 xv = ld4(x + base);
-        const float *mp = mask + (size_t)b * T;
-        const float m0 = mp[(size_t)(col + 0) << lvl], m1 = mp[(size_t)(col + 1) << lvl];
-        const float m2 = mp[(size_t)(col + 2) << lvl], m3 = mp[(size_t)(col + 3) << lvl];
-        float4 o;
-        o.x = mish_f(hv.x * a + s) * m0 + xv.x * m0;
-        o.y = mish_f(hv.y * a + s) * m1 + xv.y * m1;
-        o.z = mish_f(hv.z * a + s) * m2 + xv.z * m2;
-        o.w = mish_f(hv.w * a + s) * m3 + xv.w * m3;
-        st4(out + base, o);
+    const size_t plane = ((size_t)b * C + c) * HW;
+    const float *mp = mask + (size_t)b * T;
+    if constexpr (VEC == 8) {
+        // bf16 storage, 16-byte accesses (8 activations per lane)
+        static_assert(VEC != 8 || sizeof(AT) == 2, "VEC 8 is the bf16-storage form");
+        u32x4 hu[ITEMS], xu[ITEMS];
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int i = min(i0 + it * 256 * VEC, HW - VEC);          // (clamped: the extra loads are never used)
+            hu[it] = *reinterpret_cast<const u32x4 *>(h + plane + i);
+            xu[it] = *reinterpret_cast<const u32x4 *>(x + plane + i);
+        }
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int i = i0 + it * 256 * VEC;
+            if (i >= HW) break;
+            const int col = i % W;
+            u32x4 ou;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float m0 = mp[(size_t)(col + 2 * q) << lvl], m1 = mp[(size_t)(col + 2 * q + 1) << lvl];
+                const float h0 = __builtin_bit_cast(float, hu[it][q] << 16), h1 = __builtin_bit_cast(float, hu[it][q] & 0xffff0000u);
+                const float x0 = __builtin_bit_cast(float, xu[it][q] << 16), x1 = __builtin_bit_cast(float, xu[it][q] & 0xffff0000u);
+                const __bf16 o0 = (__bf16)(mish_f(h0 * a + s) * m0 + x0 * m0), o1 = (__bf16)(mish_f(h1 * a + s) * m1 + x1 * m1);
+                ou[q] = (unsigned)__builtin_bit_cast(unsigned short, o0) | ((unsigned)__builtin_bit_cast(unsigned short, o1) << 16);
+            }
+            *reinterpret_cast<u32x4 *>(out + plane + i) = ou;
+        }
+    } else if constexpr (VEC == 4) {
+        float4 hv[ITEMS], xv[ITEMS];
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int i = min(i0 + it * 256 * VEC, HW - VEC);
+            hv[it] = ld4(h + plane + i);
+            xv[it] = ld4(x + plane + i);
+        }
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int i = i0 + it * 256 * VEC;
+            if (i >= HW) break;
+            const int col = i % W;
+            const float m0 = mp[(size_t)(col + 0) << lvl], m1 = mp[(size_t)(col + 1) << lvl];
+            const float m2 = mp[(size_t)(col + 2) << lvl], m3 = mp[(size_t)(col + 3) << lvl];
+            float4 o;
+            o.x = mish_f(hv[it].x * a + s) * m0 + xv[it].x * m0;
+            o.y = mish_f(hv[it].y * a + s) * m1 + xv[it].y * m1;
+            o.z = mish_f(hv[it].z * a + s) * m2 + xv[it].z * m2;
+            o.w = mish_f(hv[it].w * a + s) * m3 + xv[it].w * m3;
+            st4(out + plane + i, o);
+        }
     } else {
+        static_assert(VEC != 1 || ITEMS == 1, "the scalar form takes one item per thread");
+        const int col = i0 % W;
         const float m = mask[(size_t)b * T + ((size_t)col << lvl)];
-        out[base] = (AT)(mish_f((float)h[base] * a + s) * m + (float)x[base] * m);
+        out[plane + i0] = (AT)(mish_f((float)h[plane + i0] * a + s) * m + (float)x[plane + i0] * m);
+    }
+}
+
+template <int VEC, typename AT>
+static void launch_tail_vec(const AT *h, const AT *x, const float *sc, const float *sh, const float *mask, AT *out, int B, int C,
+                            int H, int W, int T, int lvl, hipStream_t st) {
+    const int per_plane = (H * W / VEC + 255) / 256;        // one-item blocks per (sample, channel) plane
+    if (per_plane >= 8) {
+        dim3 grid((per_plane + 3) / 4, C, B);
+        hipLaunchKernelGGL((tail_identity_kernel<VEC, AT, 4>), grid, dim3(256), 0, st, h, x, sc, sh, mask, out, C, H, W, T, lvl);
+    } else {
+        dim3 grid(per_plane, C, B);
+        hipLaunchKernelGGL((tail_identity_kernel<VEC, AT, 1>), grid, dim3(256), 0, st, h, x, sc, sh, mask, out, C, H, W, T, lvl);
     }
 }
 
 template <typename AT>
 static hipError_t launch_tail_identity_t(const AT *h, const AT *x, const float *sc, const float *sh, const float *mask,
                                          AT *out, int B, int C, int H, int W, int T, int lvl, hipStream_t st) {
+    if constexpr (sizeof(AT) == 2) {
+        if (W % 8 == 0) {
+            launch_tail_vec<8, AT>(h, x, sc, sh, mask, out, B, C, H, W, T, lvl, st);
+            return hipGetLastError();
+        }
+    }
     if (W % 4 == 0) {
-        dim3 grid((H * W / 4 + 255) / 256, C, B);
-        hipLaunchKernelGGL((tail_identity_kernel<4, AT>), grid, dim3(256), 0, st, h, x, sc, sh, mask, out, C, H, W, T, lvl);
+        launch_tail_vec<4, AT>(h, x, sc, sh, mask, out, B, C, H, W, T, lvl, st);
     } else {
         dim3 grid((H * W + 255) / 256, C, B);
-        hipLaunchKernelGGL((tail_identity_kernel<1, AT>), grid, dim3(256), 0, st, h, x, sc, sh, mask, out, C, H, W, T, lvl);
+        hipLaunchKernelGGL((tail_identity_kernel<1, AT, 1>), grid, dim3(256), 0, st, h, x, sc, sh, mask, out, C, H, W, T, lvl);
     }
     return hipGetLastError();
 }
@@ -298,7 +359,8 @@ __device__ __forceinline__ float vc_update(float xt, float mean, float est, floa
     return __fmul_rn(__fsub_rn(xt, dxt), m);
 }
 
-template <typename AT>
+// PX consecutive frames per thread (T % PX == 0): bf16 storage takes PX = 4 (8-byte loads; 2-byte accesses ran at 2.9 TB/s)
+template <typename AT, int PX>
 __global__ void final_euler_kernel(const AT *__restrict__ raw, const float *__restrict__ sc,
                                    const float *__restrict__ sh, const float *__restrict__ w, const float *__restrict__ bias,
                                    const float *__restrict__ mask, int C, int F, int T, float *__restrict__ est_out,
@@ -312,23 +374,38 @@ __global__ void final_euler_kernel(const AT *__restrict__ raw, const float *__re
         sm[2 * C + i] = w[i];
     }
     __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = (blockIdx.x * 256 + threadIdx.x) * PX;
     const int FT = F * T;
     if (i >= FT) return;
     const int col = i % T;
-    const float m = mask[(size_t)b * T + col];
+    float m[PX], acc[PX];
+#pragma unroll
+    for (int j = 0; j < PX; ++j) { m[j] = mask[(size_t)b * T + col + j]; acc[j] = 0.f; }
     const AT *p = raw + (size_t)b * C * FT + i;
-    float acc = 0.f;
     for (int c = 0; c < C; ++c) {
-        const float v = mish_f((float)p[(size_t)c * FT] * sm[c] + sm[C + c]) * m * m;
-        acc = fmaf(sm[2 * C + c], v, acc);
+        float r[PX];
+        if constexpr (PX == 4 && sizeof(AT) == 2) {
+            const float4 v4 = ld4(p + (size_t)c * FT);
+            r[0] = v4.x; r[1] = v4.y; r[2] = v4.z; r[3] = v4.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < PX; ++j) r[j] = (float)p[(size_t)c * FT + j];
+        }
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const float v = mish_f(r[j] * sm[c] + sm[C + c]) * m[j] * m[j];
+            acc[j] = fmaf(sm[2 * C + c], v, acc[j]);
+        }
     }
-    const float est = (acc + bias[0]) * m;
-    const size_t o = (size_t)b * FT + i;
-    if (est_out) est_out[o] = est;
-    if (xt) {
-        if (vc.mode == 0) xt[o] = euler_update(xt[o], mu[o], est, m, noise ? noise[o] : 0.f, noise != nullptr, beta, h, sq);
-        else xt[o] = vc_update(xt[o], mu[o], est, m, noise ? noise[o] : 0.f, vc.mode, vc.cm, vc.k1, vc.bh, vc.sigma);
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+        const float est = (acc[j] + bias[0]) * m[j];
+        const size_t o = (size_t)b * FT + i + j;
+        if (est_out) est_out[o] = est;
+        if (xt) {
+            if (vc.mode == 0) xt[o] = euler_update(xt[o], mu[o], est, m[j], noise ? noise[o] : 0.f, noise != nullptr, beta, h, sq);
+            else xt[o] = vc_update(xt[o], mu[o], est, m[j], noise ? noise[o] : 0.f, vc.mode, vc.cm, vc.k1, vc.bh, vc.sigma);
+        }
     }
 }
 
@@ -340,11 +417,15 @@ hipError_t launch_final_euler(const void *raw, const float *sc, const float *sh,
     VcStep v;
     v.mode = 0; v.cm = v.k1 = v.bh = v.sigma = 0.f;
     if (vc) v = *vc;
-    if (act_bf16)
-        hipLaunchKernelGGL(final_euler_kernel<__bf16>, grid, dim3(256), (size_t)3 * C * sizeof(float), st, (const __bf16 *)raw, sc, sh,
+    if (act_bf16 && T % 4 == 0) {
+        dim3 grid4((F * T / 4 + 255) / 256, B);
+        hipLaunchKernelGGL((final_euler_kernel<__bf16, 4>), grid4, dim3(256), (size_t)3 * C * sizeof(float), st, (const __bf16 *)raw, sc, sh,
+                           w, bias, mask, C, F, T, est_out, xt, mu, noise, beta, h, sq, v);
+    } else if (act_bf16)
+        hipLaunchKernelGGL((final_euler_kernel<__bf16, 1>), grid, dim3(256), (size_t)3 * C * sizeof(float), st, (const __bf16 *)raw, sc, sh,
                            w, bias, mask, C, F, T, est_out, xt, mu, noise, beta, h, sq, v);
     else
-        hipLaunchKernelGGL(final_euler_kernel<float>, grid, dim3(256), (size_t)3 * C * sizeof(float), st, (const float *)raw, sc, sh,
+        hipLaunchKernelGGL((final_euler_kernel<float, 1>), grid, dim3(256), (size_t)3 * C * sizeof(float), st, (const float *)raw, sc, sh,
                            w, bias, mask, C, F, T, est_out, xt, mu, noise, beta, h, sq, v);
     return hipGetLastError();
 }

@@ -113,8 +113,8 @@ struct gtts_plan {
     size_t fw_off, fb_off;     // final_conv weight / bias (fp32)
     // extra (non-program) launches, profiled as ops n_ops .. n_ops+3: prep_input, time_mlp, final_euler, mul_mask
     // profiling
-    bool prof_on = false;
-    struct ProfRec { int op; hipEvent_t a, b; };
+    int prof_on = 0;           // 0 off, 1 per-op durations (unsplit), 2 timeline (sub-batch streams stay on; gtts_profile_timeline)
+    struct ProfRec { int op; hipEvent_t a, b; int stream; };
     std::vector<ProfRec> prof;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
     // Caller-owned side streams for the sampler's sub-batch split (gtts_plan_set_streams); the fork / join events
@@ -783,7 +783,9 @@ struct ProfScope {
         std::pair<hipEvent_t, hipEvent_t> ev;
         if (!p->prof_pool.empty()) { ev = p->prof_pool.back(); p->prof_pool.pop_back(); }
         else { if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) return; }
-        p->prof.push_back({op, ev.first, ev.second});
+        int si = 0;                                            // 0: the call's stream, 1 + h: side stream h
+        for (int h = 0; h < p->nsub; ++h) if (p->sub[h] == s) si = 1 + h;
+        p->prof.push_back({op, ev.first, ev.second, si});
         idx = (int)p->prof.size() - 1;
         (void)hipEventRecord(ev.first, st);
     }
@@ -998,7 +1000,7 @@ static int enqueue_reverse_diffusion(gtts_plan *p, const void *packed, const flo
     // overlap MFMA-bound ones.  Results are bit-identical to the unsplit run (no operation mixes batch entries).
     // per-op profiling (gtts_profile_enable) runs the batch unsplit: one launch per op owns the GPU, so an op's
     // HIP-event duration and its whole-batch algorithmic work describe the same thing
-    const int nhalf = p->prof_on ? 1 : sampler_parts(p, B);
+    const int nhalf = p->prof_on == 1 ? 1 : sampler_parts(p, B);
     const int Bh0 = (B + nhalf - 1) / nhalf;
     layout_workspace(p, Bh0, T, std::max(Bh0, 4096));
     const size_t ws_half = align_up(p->ws_bytes, 256);
@@ -1468,7 +1470,24 @@ extern "C" int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, con
 
 extern "C" int gtts_profile_enable(gtts_plan *plan, int on) {
     if (!plan) return fail(GTTS_E_NULL, "null plan");
-    plan->prof_on = on != 0;
+    plan->prof_on = on == 2 ? 2 : (on != 0 ? 1 : 0);
+    return GTTS_OK;
+}
+
+extern "C" int gtts_profile_timeline(gtts_plan *plan, int cap, int *op, int *stream, double *t0_ms, double *t1_ms, int *n) {
+    if (!plan || !op || !stream || !t0_ms || !t1_ms || !n) return fail(GTTS_E_NULL, "gtts_profile_timeline: null argument");
+    *n = 0;
+    if (plan->prof.empty()) return GTTS_OK;
+    const hipEvent_t base = plan->prof[0].a;
+    for (auto &r : plan->prof) {
+        HIPCHK(hipEventSynchronize(r.b));
+        float a = 0.f, b = 0.f;
+        HIPCHK(hipEventElapsedTime(&a, base, r.a));
+        HIPCHK(hipEventElapsedTime(&b, base, r.b));
+        if (*n < cap) { op[*n] = r.op; stream[*n] = r.stream; t0_ms[*n] = a; t1_ms[*n] = b; ++*n; }
+        plan->prof_pool.push_back({r.a, r.b});
+    }
+    plan->prof.clear();
     return GTTS_OK;
 }
 

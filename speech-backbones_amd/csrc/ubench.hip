@@ -47,18 +47,38 @@ __global__ __launch_bounds__(256, 2) void ubench_mfma_kernel(const unsigned shor
     out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
 }
 
-// mode 0: c = a (copy, 8 B per element moved); 1: c = a + 1.5 b (triad, 12 B); 2: read-only sum of a (4 B)
-template <int MODE>
-__global__ __launch_bounds__(256) void ubench_hbm_kernel(const float4 *a, const float4 *b, float4 *c, size_t n4, float *sink) {
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+// mode 0: c = a (copy, 8 B per element moved); 1: c = a + 1.5 b (triad, 12 B); 2: read-only sum of a (4 B); NT: nontemporal
+// loads / stores.  Four 16-byte loads per stream in flight per lane (a lane's items are a whole grid apart: every wave access
+// is 1 KB contiguous).
+template <int MODE, int NT>
+__global__ __launch_bounds__(256) void ubench_hbm_kernel(const f32x4 *a, const f32x4 *b, f32x4 *c, size_t n4, float *sink) {
+    constexpr int U = 4;
     const size_t stride = (size_t)gridDim.x * 256;
-    float4 s = {0.f, 0.f, 0.f, 0.f};
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-        const float4 x = a[i];
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    auto ld = [](const f32x4 *p) { return NT ? __builtin_nontemporal_load(p) : *p; };
+    auto st = [](f32x4 v, f32x4 *p) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; };
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (U - 1) * stride < n4; i += U * stride) {
+        f32x4 x[U], y[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = ld(a + i + u * stride);
+        if (MODE == 1) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) y[u] = ld(b + i + u * stride);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (MODE == 0) st(x[u], c + i + u * stride);
+            else if (MODE == 1) st(x[u] + 1.5f * y[u], c + i + u * stride);
+            else s += x[u];
+        }
+    }
+    for (; i < n4; i += stride) {
+        const f32x4 x = a[i];
         if (MODE == 0) c[i] = x;
-        else if (MODE == 1) {
-            const float4 y = b[i];
-            c[i] = float4{x.x + 1.5f * y.x, x.y + 1.5f * y.y, x.z + 1.5f * y.z, x.w + 1.5f * y.w};
-        } else { s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w; }
+        else if (MODE == 1) c[i] = x + 1.5f * b[i];
+        else s += x;
     }
     if (MODE == 2 && s.x + s.y + s.z + s.w == 123.456f) sink[0] = s.x;     // keeps the loads alive, (almost) never taken
 }
@@ -80,15 +100,18 @@ int gtts_ubench_mfma(const void *src, size_t src_bytes, float *out, int workgrou
 }
 
 int gtts_ubench_hbm(const float *a, const float *b, float *c, size_t n, int mode, int workgroups, double *bytes, gtts_stream_t stream) {
-    if (!a || (mode == 1 && !b) || !c) return gtts::set_error(GTTS_E_NULL, "gtts_ubench_hbm: null buffer");
-    if (n < 4 || n % 4 != 0 || workgroups <= 0 || mode < 0 || mode > 2) return gtts::set_error(GTTS_E_SHAPE, "gtts_ubench_hbm: bad sizes");
-    const float4 *a4 = reinterpret_cast<const float4 *>(a), *b4 = reinterpret_cast<const float4 *>(b);
-    float4 *c4 = reinterpret_cast<float4 *>(c);
+    const int m = mode & 3, nt = mode >> 2;
+    if (!a || (m == 1 && !b) || !c) return gtts::set_error(GTTS_E_NULL, "gtts_ubench_hbm: null buffer");
+    if (n < 4 || n % 4 != 0 || workgroups <= 0 || mode < 0 || m > 2 || nt > 1) return gtts::set_error(GTTS_E_SHAPE, "gtts_ubench_hbm: bad sizes");
+    const gtts::f32x4 *a4 = reinterpret_cast<const gtts::f32x4 *>(a), *b4 = reinterpret_cast<const gtts::f32x4 *>(b);
+    gtts::f32x4 *c4 = reinterpret_cast<gtts::f32x4 *>(c);
     hipStream_t st = (hipStream_t)stream;
-    if (mode == 0) hipLaunchKernelGGL((gtts::ubench_hbm_kernel<0>), dim3(workgroups), dim3(256), 0, st, a4, b4, c4, n / 4, c);
-    else if (mode == 1) hipLaunchKernelGGL((gtts::ubench_hbm_kernel<1>), dim3(workgroups), dim3(256), 0, st, a4, b4, c4, n / 4, c);
-    else hipLaunchKernelGGL((gtts::ubench_hbm_kernel<2>), dim3(workgroups), dim3(256), 0, st, a4, b4, c4, n / 4, c);
-    if (bytes) *bytes = (double)n * (mode == 0 ? 8.0 : (mode == 1 ? 12.0 : 4.0));
+#define GTTS_UB(M, N) hipLaunchKernelGGL((gtts::ubench_hbm_kernel<M, N>), dim3(workgroups), dim3(256), 0, st, a4, b4, c4, n / 4, c)
+    if (m == 0) { if (nt) GTTS_UB(0, 1); else GTTS_UB(0, 0); }
+    else if (m == 1) { if (nt) GTTS_UB(1, 1); else GTTS_UB(1, 0); }
+    else { if (nt) GTTS_UB(2, 1); else GTTS_UB(2, 0); }
+#undef GTTS_UB
+    if (bytes) *bytes = (double)n * (m == 0 ? 8.0 : (m == 1 ? 12.0 : 4.0));
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? GTTS_OK : gtts::set_error(GTTS_E_HIP, hipGetErrorString(e));
 }

@@ -59,3 +59,27 @@ for prio in ((0, 0), (0, -1), (-1, 0)):
     t3 = min(run(ew, ew, sa, sb) for _ in range(3))
     print("prio conv/ew %s: conv %.1f us  ew %.1f us  both %.1f us (sum %.1f, max %.1f)  conv+conv %.1f  ew+ew %.1f" %
           (prio, ta * 1e3, tb * 1e3, tc * 1e3, (ta + tb) * 1e3, max(ta, tb) * 1e3, t2 * 1e3, t3 * 1e3), flush=True)
+
+# ---- the same question with a kernel that provably leaves room: the MFMA micro-benchmark at ONE 4-wave workgroup per CU
+# (154 VGPRs, no LDS) beside the element-wise pass.  If this pair overlaps and conv || ew does not, the dispatcher is what
+# serialises them; if neither overlaps, the power budget is (an MFMA-saturated chip has no headroom for HBM traffic).
+import ctypes
+lib = L.lib()
+rnd = torch.randn(1 << 20, generator=g).to(torch.bfloat16).to(dev)
+for wgs in (256, 512):
+    sink = torch.empty(int(lib.gtts_ubench_mfma_out_floats(wgs)), dtype=torch.float32, device=dev)
+    fl = ctypes.c_double(0.0)
+    iters = 1700 if wgs == 256 else 850
+
+    def mf():
+        L._check(lib.gtts_ubench_mfma(L._ptr(rnd), ctypes.c_size_t(rnd.numel() * 2), L._ptr(sink), wgs, iters, ctypes.byref(fl),
+                                      L._stream()), "ubench")
+
+    sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    for _ in range(2):
+        run(mf, ew, sa, sb)
+    ta = min(run(mf, None, sa, sb) for _ in range(3))
+    tb = min(run(None, ew, sa, sb) for _ in range(3))
+    tc = min(run(mf, ew, sa, sb) for _ in range(3))
+    print("mfma ubench (%d WGs) %.1f us  ew %.1f us  both %.1f us (sum %.1f, max %.1f)" %
+          (wgs, ta * 1e3, tb * 1e3, tc * 1e3, (ta + tb) * 1e3, max(ta, tb) * 1e3), flush=True)
