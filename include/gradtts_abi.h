@@ -402,7 +402,8 @@ int gtts_profile_timeline(gtts_plan *plan, int cap, int *op, int *stream, double
  * Both enqueue ONE kernel on `stream`; the caller times it (HIP events) and divides.  Nothing on the sampling path calls them.
  * gtts_ubench_mfma: `workgroups` x 4 waves each issue iters x 8 independent v_mfma_f32_32x32x16_bf16 whose operand fragments
  *   are read from src (>= 4096 bytes of bf16 data: pass random values -- the chip clocks to its power budget and all-zero
- *   operands overstate what live data reaches); out: gtts_ubench_mfma_out_floats(workgroups) floats; *flops = FLOPs enqueued.
+ *   operands overstate what live data reaches); out: gtts_ubench_mfma_out_floats(workgroups) floats; *flops = FLOPs enqueued;
+ *   iters < 0: |iters| sweeps of 16 independent v_mfma_f32_16x16x32_bf16 instead (the other bf16 shape).
  * gtts_ubench_hbm: mode 0 c = a (8 bytes per element), 1 c = a + 1.5 b (12), 2 read-only sweep of a (4), + 4: the same with
  *   nontemporal loads / stores; n floats, a multiple of 4, buffers 16-byte aligned; *bytes = bytes the launch moves. */
 size_t gtts_ubench_mfma_out_floats(int workgroups);

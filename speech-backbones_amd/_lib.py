@@ -1364,6 +1364,10 @@ def measured_ceilings(device, seconds=2.0):
             reps = max(3, int(seconds * 0.3 / max(t1, 1e-6)))      # long enough for the clock to settle at its power budget
             t = timed(fn, reps)
             out["mfma_bf16_tflops_%s" % name] = flops.value / t * 1e-12
+        fn = lambda: _check(L.gtts_ubench_mfma(_ptr(rnd), ctypes.c_size_t(rnd.numel() * 2), _ptr(sink), wgs, -iters,
+                                               ctypes.byref(flops), st), "gtts_ubench_mfma")
+        t1 = timed(fn, 3)
+        out["mfma_bf16_16x16x32_tflops_random"] = flops.value / timed(fn, max(3, int(seconds * 0.3 / max(t1, 1e-6)))) * 1e-12
         # what the vendor's GEMM library reaches on the same chip with the same kind of data (hipBLASLt through torch.matmul,
         # 8192^3 bf16): the practical ceiling of an LDS-fed MFMA kernel, beside the register-only stream above
         m = 8192

@@ -37,8 +37,11 @@ struct C1Args {
 // Occupancy by tile: the 32- and 64-row tiles (HiFi-GAN's last two stages, the encoders' small layers) are bandwidth /
 // latency bound -- a workgroup's whole life is a handful of dependent memory round trips -- and want many workgroups per CU;
 // the 128-row tile is MFMA-bound and keeps the deeper (two chunks ahead) activation prefetch instead.
+#ifndef GTTS_C1_WAVES128
+#define GTTS_C1_WAVES128 2
+#endif
 template <int WM, int WN, int MF, int TPS, int AITER>
-__global__ __launch_bounds__(256, (WM * MF == 1) ? 4 : (WM * MF == 2 ? 3 : 2)) void conv1d_mfma_kernel(const C1Args a) {
+__global__ __launch_bounds__(256, (WM * MF == 1) ? 4 : (WM * MF == 2 ? 3 : GTTS_C1_WAVES128)) void conv1d_mfma_kernel(const C1Args a) {
     constexpr int MT = WM * MF * 32, NT = WN * 64, NKG = 2;
     constexpr bool PF2 = MT >= 128;                             // activation prefetch distance 2 (else 1)
     constexpr int WBLK16 = 2 * TPS * NKG * MT;                 // 16-byte units per weight stage (hi + lo)
@@ -199,10 +202,6 @@ __global__ __launch_bounds__(256, (WM * MF == 1) ? 4 : (WM * MF == 2 ? 3 : 2)) v
     // S is a power of two (a.ls = log2 S): row m -> (channel m >> ls, output phase m & (S-1)); 32-bit offsets inside a sample.
     const int Lout = a.Lin << a.ls;
     const size_t ob = (size_t)b * a.cout * Lout;
-    float *outb = a.out + ob;
-    const float *resb = a.res ? a.res + ob : nullptr;
-    const float *accb = a.accsrc ? a.accsrc + ob : nullptr;
-    const float *omb = a.out_mask ? a.out_mask + (size_t)b * Lout : nullptr;
     float bv[MF][16];
 #pragma unroll
     for (int mi = 0; mi < MF; ++mi)
@@ -211,6 +210,107 @@ __global__ __launch_bounds__(256, (WM * MF == 1) ? 4 : (WM * MF == 2 ? 3 : 2)) v
             const int m = cot * MT + m0 + mi * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kgl;
             bv[mi][rg] = a.bias[min(m, M - 1) >> a.ls];
         }
+    if (a.S == 1 && M % MT == 0) {
+        // Plain convolutions on whole row tiles (every ResBlock / encoder layer): residual, running sum and output go through
+        // buffer descriptors of this sample's tensors -- per-lane byte offset = (the lane's 4-row sub-block, position), the row
+        // offset of each of the 16 x MF values in an SGPR -- so the 64 (x 3 arrays) accesses of a lane need no 64-bit VALU address
+        // arithmetic (with plain pointers the residual convolutions of a ResBlock pair took 1.5 - 2x the time of the first ones:
+        // profiles/r04_hifigan_layers.txt); positions past the end get an out-of-range offset (loads return 0, stores are dropped).
+        const int tbytes = a.cout * Lout * 4;
+        auto rsrc = [&](const float *p) {
+            const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+            return __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<void *>(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(u >> 32)) << 32) |
+                                         (unsigned)__builtin_amdgcn_readfirstlane((unsigned)u)),
+                0, __builtin_amdgcn_readfirstlane(tbytes), 0x00020000);
+        };
+        const __amdgpu_buffer_rsrc_t rs_out = rsrc(a.out + ob);
+        const __amdgpu_buffer_rsrc_t rs_res = rsrc(a.res ? a.res + ob : a.out + ob);
+        const __amdgpu_buffer_rsrc_t rs_acc = rsrc(a.accsrc ? a.accsrc + ob : a.out + ob);
+        const int row0 = __builtin_amdgcn_readfirstlane(cot * MT + m0);
+        const float *omb = a.out_mask ? a.out_mask + (size_t)b * Lout : nullptr;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int q = q0 + wn * 64 + ni * 32 + l31;
+            const int voff = q < a.Lin ? (4 * kgl * Lout + q) * 4 : tbytes;       // (>= num_records: out of range whatever the row offset)
+            const float om = (omb && q < a.Lin) ? omb[q] : 1.f;
+#pragma unroll
+            for (int mi = 0; mi < MF; ++mi) {
+                float rv[16], av[16];
+                if (a.res) {
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg)
+                        rv[rg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                     rs_res, voff, (row0 + mi * 32 + (rg & 3) + 8 * (rg >> 2)) * Lout * 4, 0));
+                }
+                if (a.accmode != 0) {
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg)
+                        av[rg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                     rs_acc, voff, (row0 + mi * 32 + (rg & 3) + 8 * (rg >> 2)) * Lout * 4, 0));
+                }
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    float v = acc[mi][ni][rg] + bv[mi][rg];
+                    if (a.res) v = v + rv[rg];
+                    if (a.accmode == 1) v = av[rg] + v;
+                    else if (a.accmode == 2) v = __fdiv_rn(av[rg] + v, a.div);
+                    if (omb) v *= om;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs_out, voff,
+                                                          (row0 + mi * 32 + (rg & 3) + 8 * (rg >> 2)) * Lout * 4, 0);
+                }
+            }
+        }
+        return;
+    }
+    if (a.S >= 2 && M % MT == 0 && !a.res && a.accmode == 0 && !a.out_mask) {
+        // ConvTranspose1d (every upsampling layer): the four consecutive rows (rg & 3) of a C/D fragment are four consecutive
+        // output phases of one channel (S >= 4) or two phases of two adjacent channels (S == 2): one 16-byte / two 8-byte
+        // buffer stores per lane instead of four scalar stores with 64-bit address arithmetic each.
+        const int tbytes = a.cout * Lout * 4;
+        const unsigned long long u = reinterpret_cast<unsigned long long>(a.out + ob);
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<void *>(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(u >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((unsigned)u)),
+            0, __builtin_amdgcn_readfirstlane(tbytes), 0x00020000);
+        typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int q = q0 + wn * 64 + ni * 32 + l31;
+            const bool ok = q < a.Lin;
+            const int qs = q << a.ls;
+#pragma unroll
+            for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int m4 = cot * MT + m0 + mi * 32 + 8 * g + 4 * kgl;          // first of the lane's four rows
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = acc[mi][ni][4 * g + i] + bv[mi][4 * g + i];
+                    if (a.ls >= 2) {
+                        const int co = m4 >> a.ls, r0 = m4 & (a.S - 1);
+                        const int voff = ok ? (co * Lout + qs + r0) * 4 : tbytes;
+                        u32x4 pk;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) pk[i] = __builtin_bit_cast(unsigned, v[i]);
+                        __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, voff, 0, 0);
+                    } else {
+                        const int co = m4 >> 1;
+                        const int voff = ok ? (co * Lout + qs) * 4 : tbytes;
+                        u32x2 p0, p1;
+                        p0[0] = __builtin_bit_cast(unsigned, v[0]); p0[1] = __builtin_bit_cast(unsigned, v[1]);
+                        p1[0] = __builtin_bit_cast(unsigned, v[2]); p1[1] = __builtin_bit_cast(unsigned, v[3]);
+                        __builtin_amdgcn_raw_buffer_store_b64(p0, rs_out, voff, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(p1, rs_out, ok ? voff + Lout * 4 : tbytes, 0, 0);
+                    }
+                }
+        }
+        return;
+    }
+    float *outb = a.out + ob;
+    const float *resb = a.res ? a.res + ob : nullptr;
+    const float *accb = a.accsrc ? a.accsrc + ob : nullptr;
+    const float *omb = a.out_mask ? a.out_mask + (size_t)b * Lout : nullptr;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int q = q0 + wn * 64 + ni * 32 + l31;

@@ -48,6 +48,44 @@ __global__ __launch_bounds__(256, 2) void ubench_mfma_kernel(const unsigned shor
 }
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+// The same stream with v_mfma_f32_16x16x32_bf16 (4 accumulator registers per block, K = 32): does the other bf16 shape sustain a
+// different rate under the power budget?  NA x NB blocks of 16 x 16.
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+template <int NA, int NB>
+__global__ __launch_bounds__(256, 2) void ubench_mfma16_kernel(const unsigned short *src, size_t src_elems, float *out, int iters) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    bf16x8 a[NA], b[NB];
+#pragma unroll
+    for (int i = 0; i < NA + NB; ++i) {
+        const size_t off = ((wave * (NA + NB) + i) * 64 + lane) * 8 % (src_elems - 8);
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(src + (off & ~(size_t)7));
+        if (i < NA) a[i] = __builtin_bit_cast(bf16x8, v);
+        else b[i - NA] = __builtin_bit_cast(bf16x8, v);
+    }
+    f32x4v acc[NA][NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s += acc[i][j][r];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 // mode 0: c = a (copy, 8 B per element moved); 1: c = a + 1.5 b (triad, 12 B); 2: read-only sum of a (4 B); NT: nontemporal
 // loads / stores.  Four 16-byte loads per stream in flight per lane (a lane's items are a whole grid apart: every wave access
 // is 1 KB contiguous).
@@ -91,10 +129,16 @@ size_t gtts_ubench_mfma_out_floats(int workgroups) { return workgroups > 0 ? (si
 
 int gtts_ubench_mfma(const void *src, size_t src_bytes, float *out, int workgroups, int iters, double *flops, gtts_stream_t stream) {
     if (!src || !out) return gtts::set_error(GTTS_E_NULL, "gtts_ubench_mfma: null buffer");
-    if (src_bytes < 4096 || workgroups <= 0 || iters <= 0) return gtts::set_error(GTTS_E_SHAPE, "gtts_ubench_mfma: bad sizes");
-    hipLaunchKernelGGL((gtts::ubench_mfma_kernel<2, 4>), dim3(workgroups), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const unsigned short *>(src), src_bytes / 2, out, iters);
-    if (flops) *flops = (double)workgroups * 4.0 * iters * 8.0 * (2.0 * 32 * 32 * 16);
+    if (src_bytes < 4096 || workgroups <= 0 || iters == 0) return gtts::set_error(GTTS_E_SHAPE, "gtts_ubench_mfma: bad sizes");
+    if (iters > 0) {
+        hipLaunchKernelGGL((gtts::ubench_mfma_kernel<2, 4>), dim3(workgroups), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const unsigned short *>(src), src_bytes / 2, out, iters);
+        if (flops) *flops = (double)workgroups * 4.0 * iters * 8.0 * (2.0 * 32 * 32 * 16);
+    } else {        // iters < 0: the 16 x 16 x 32 shape, 4 x 4 blocks per wave, |iters| sweeps
+        hipLaunchKernelGGL((gtts::ubench_mfma16_kernel<4, 4>), dim3(workgroups), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const unsigned short *>(src), src_bytes / 2, out, -iters);
+        if (flops) *flops = (double)workgroups * 4.0 * (-iters) * 16.0 * (2.0 * 16 * 16 * 32);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? GTTS_OK : gtts::set_error(GTTS_E_HIP, hipGetErrorString(e));
 }
