@@ -125,14 +125,16 @@ def test_shard_helpers():
     assert fb[0][0] == 0 and fb[-1][1] == 6 and fb[0][1] == fb[1][0]
 
 
-def _bcast_worker(q):
-    """gtts_bcast_weights (the C ABI's RCCL entry point for non-torch hosts) carrying real bytes through a one-rank
-    ncclComm_t created with ctypes on the RCCL the process already has loaded."""
+def _bcast_worker(rank, world, uid_q, q):
+    """gtts_bcast_weights (the C ABI's RCCL entry point for non-torch hosts) carrying real bytes through an ncclComm_t created
+    with ctypes on the RCCL the process already has loaded.  world == 2 (two visible GPUs): rank 1 starts from zeros and must end
+    up with rank 0's bytes -- a broadcast that moved nothing fails.  world == 1 (the one-GPU test box): the call path only."""
     import ctypes
     import sys
     sys.path.insert(0, ROOT)
     S = importlib.import_module("speech-backbones_amd")
-    dev = torch.device("cuda:0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
     torch.zeros(1, device=dev)
     path = None
     for line in open("/proc/self/maps"):
@@ -148,28 +150,37 @@ def _bcast_worker(q):
     rccl.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
     rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
     rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
-    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    if rank == 0:
+        assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+        for _ in range(world - 1):
+            uid_q.put(bytes(ctypes.string_at(ctypes.byref(uid), 128)))
+    else:
+        ctypes.memmove(ctypes.byref(uid), uid_q.get(timeout=120), 128)
     comm = ctypes.c_void_p()
-    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), world, uid, rank) == 0
     g = torch.Generator().manual_seed(0)
-    blob = torch.randint(0, 256, (3 * 1024 * 1024 + 17,), dtype=torch.uint8, generator=g).to(dev)
-    want = blob.clone()
+    want = torch.randint(0, 256, (3 * 1024 * 1024 + 17,), dtype=torch.uint8, generator=g).to(dev)
+    blob = want.clone() if rank == 0 else torch.zeros_like(want)
     L = S._lib.lib()
     rc = L.gtts_bcast_weights(ctypes.c_void_p(blob.data_ptr()), blob.numel(), 0, comm, S._lib._stream())
     torch.cuda.synchronize()
     ok = rc == 0 and bool(torch.equal(blob, want))
     err = L.gtts_last_error().decode() if rc else ""
     rccl.ncclCommDestroy(comm)
-    q.put((ok, rc, err, path))
+    q.put((ok, rc, err, path, rank))
 
 
 @pytest.mark.gpu
 def test_bcast_weights_carries_bytes_through_rccl():
+    world = 2 if torch.cuda.device_count() >= 2 else 1
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    p = ctx.Process(target=_bcast_worker, args=(q,))
-    p.start()
-    ok, rc, err, path = q.get(timeout=300)
-    p.join(timeout=60)
-    print("RCCL library:", path)
-    assert ok, (rc, err)
+    q, uid_q = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, world, uid_q, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    print("RCCL library:", res[0][3], " ranks:", world)
+    for ok, rc, err, path, rank in res:
+        assert ok, (rank, rc, err)

@@ -384,3 +384,44 @@ def test_loss_and_gradients_match_reference_golden_on_gpu(S, dev, tag, n_spks):
     dec = dec.to(dev)
     worst = check_against_golden_grads(dec, G, tag, dev, 2e-4)
     print("loss_t gradients vs the reference golden (%d speakers): worst %.2e (%s)" % (n_spks, worst[1], worst[0]))
+
+
+def test_weights_edited_through_data_are_seen_by_the_next_step(S, dev):
+    """Writes through `p.data` (EMA swaps, manual SGD) do not bump Tensor._version.  The packed copies the training convolutions
+    multiply with are therefore valid for ONE estimator call only (new_pack_generation): after such an edit the next forward
+    must use the new weights in the forward AND in the data-gradient convolutions, exactly like a fresh module would."""
+    M = importlib.import_module("speech-backbones_amd.model.diffusion")
+    sd = O.make_estimator_state(seed=4, rezero_g=0.3)
+    inp = O.make_inputs(2, 64, seed=8)
+    t = torch.tensor([0.35, 0.8]).to(dev)
+    xt, mask, mu = (inp[k].to(dev) for k in ("z", "mask", "mu"))
+
+    def run(model):
+        model.zero_grad(set_to_none=True)
+        est = model.estimator(xt * mask, mask, mu, t)
+        loss = (est ** 2).mean()
+        loss.backward()
+        return float(loss.detach()), model.estimator.downs[0][0].block1.block[0].weight.grad.clone()
+
+    a = M.Diffusion(80, 64, 1, 64, 0.05, 20.0, 1000)
+    a.estimator.load_state_dict(sd, strict=True)
+    a = a.to(dev)
+    l0, _ = run(a)
+    edited = {}
+    with torch.no_grad():
+        for name, p in a.estimator.named_parameters():
+            if name.endswith("block.0.weight") or name.endswith("res_conv.weight") or name.endswith("to_qkv.weight"):
+                v0 = p._version
+                p.data.mul_(1.25)                   # no version bump
+                assert p._version == v0
+                edited[name] = p.detach().clone()
+    assert edited
+    l1, g1 = run(a)
+    fresh = M.Diffusion(80, 64, 1, 64, 0.05, 20.0, 1000)
+    sd2 = {k: (edited[k].cpu() if k in edited else v) for k, v in sd.items()}
+    fresh.estimator.load_state_dict(sd2, strict=True)
+    fresh = fresh.to(dev)
+    l2, g2 = run(fresh)
+    assert abs(l1 - l0) > 1e-3 * abs(l0), "the edit must change the loss"
+    # (same kernels, same data: equal up to the run-to-run freedom of the few stock ops left -- the [B, 64] time MLP)
+    assert abs(l1 - l2) <= 1e-6 * abs(l2) and relerr(g1, g2) <= 1e-5, (l0, l1, l2, relerr(g1, g2))
