@@ -1418,7 +1418,7 @@ extern "C" int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, con
         switch (i - n) {
             case XOP_PREP: s_label = "prep_input"; s_kernel = abf ? "gtts::prep_input_kernel<__bf16>" : "gtts::prep_input_kernel<float>"; by = (4.0 + ab) * FT * plan->cin0; break;
             case XOP_TIME: s_label = "time_mlp"; s_kernel = "gtts::time_mlp_kernel"; break;
-            case XOP_FINAL: s_label = "final_conv+euler"; s_kernel = abf ? "gtts::final_euler_kernel<__bf16>" : "gtts::final_euler_kernel<float>";
+            case XOP_FINAL: s_label = "final_conv+euler"; s_kernel = abf ? (T % 4 == 0 ? "gtts::final_euler_kernel<__bf16, 4>" : "gtts::final_euler_kernel<__bf16, 1>") : "gtts::final_euler_kernel<float, 1>";
                 fl = 2.0 * plan->cfg.dim * FT; by = FT * (ab * plan->cfg.dim + 16.0); break;
             case XOP_MULMASK: s_label = "xt=z*mask"; s_kernel = "gtts::mul_mask_kernel"; by = 8.0 * FT; break;
             case XOP_SPK: s_label = "spk_mlp"; s_kernel = "gtts::spk_mlp_kernel"; break;
@@ -1441,7 +1441,16 @@ extern "C" int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, con
                 break;
             }
             case OP_GNFIN: s_kernel = "gtts::gn_finalize_kernel"; break;
-            case OP_TAILID: s_kernel = abf ? "gtts::tail_identity_kernel<4, __bf16>" : "gtts::tail_identity_kernel<4, float>"; by = ab * B * o.C * Hi * Wi * 3; break;
+            case OP_TAILID: {
+                // the instance launch_tail_identity picks (misc.hip): vector width by storage type / width, 4 items per thread on big planes
+                const int vec = (abf && (int)Wi % 8 == 0) ? 8 : ((int)Wi % 4 == 0 ? 4 : 1);
+                const int items = (vec > 1 && ((int)(Hi * Wi) / vec + 255) / 256 >= 8) ? 4 : 1;
+                char nb[96];
+                snprintf(nb, sizeof nb, "gtts::tail_identity_kernel<%d, %s, %d>", vec, abf ? "__bf16" : "float", items);
+                s_kernel = nb;
+                by = ab * B * o.C * Hi * Wi * 3;
+                break;
+            }
             case OP_ACTX: {
                 char nb[96];
                 if (attn_head_per_wave(o.C))
