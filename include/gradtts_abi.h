@@ -335,6 +335,16 @@ size_t gtts_conv_resample_packed_bytes(int cin, int cout, int up);
 int gtts_conv_resample_pack(const float *w, void *packed, int cin, int cout, int up, gtts_stream_t stream);
 int gtts_conv_resample(const float *x, const float *mask, const void *packed, const float *bias, float *y, int B, int cin, int cout,
                        int H, int W, int up, gtts_stream_t stream);
+/* ABI 4: every weight pack of a training step in ONE launch.  item.kind: 0 Block 3x3 (gtts_conv3x3_pack), 1 1x1 (gtts_conv1x1_pack),
+ * 2 Downsample, 3 Upsample (gtts_conv_resample_pack), 4 Downsample's data gradient (its forward weight [cout][cin][3][3] packed as the
+ * zero-padded 4x4 transposed convolution; cin / cout those of the GRADIENT convolution); transposed as in the single-pack calls
+ * (kinds 0 / 1).  gtts_pack_batch_describe turns n items into a descriptor table in HOST memory (gtts_pack_batch_desc_bytes(n)
+ * bytes) and returns the launch width; the caller keeps a device copy of the table (addresses are stable across steps) and calls
+ * gtts_pack_batch at the top of every step. */
+typedef struct gtts_pack_item { const float *w; void *packed; int kind, cin, cout, transposed; } gtts_pack_item;
+size_t gtts_pack_batch_desc_bytes(int n);
+int gtts_pack_batch_describe(const gtts_pack_item *items, int n, void *desc_host, int *grid_x);
+int gtts_pack_batch(const void *desc_dev, int n, int grid_x, gtts_stream_t stream);
 int gtts_zero_insert2(const float *in, float *out, int B, int C, int h, int w, gtts_stream_t stream);
 /* out [B,4C,h,w] = the four stride-2 phases of in [B,C,2h,2w], channel block (pr * 2 + pc) = rows 2y + 1 - pr, columns 2x + 1 - pc:
  * Upsample's data / weight gradient are the 3x3 stride-1 convolution / weight gradient over these planes. */

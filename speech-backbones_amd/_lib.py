@@ -43,6 +43,11 @@ class VocCfg(ctypes.Structure):
                 ("resblock_dilations", (ctypes.c_int * 3) * 8), ("resblock_type", ctypes.c_int)]
 
 
+class PackItem(ctypes.Structure):           # gtts_pack_item
+    _fields_ = [("w", ctypes.c_void_p), ("packed", ctypes.c_void_p), ("kind", ctypes.c_int), ("cin", ctypes.c_int),
+                ("cout", ctypes.c_int), ("transposed", ctypes.c_int)]
+
+
 def lib():
     """Load the HIP library (once).  Fails loudly when it has not been built."""
     global _lib
@@ -183,6 +188,10 @@ def lib():
         L.gtts_profile_collect.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]
         L.gtts_profile_timeline.argtypes = [vp, i, ctypes.POINTER(i), ctypes.POINTER(i), ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i)]
+        L.gtts_pack_batch_desc_bytes.argtypes = [i]
+        L.gtts_pack_batch_desc_bytes.restype = sz
+        L.gtts_pack_batch_describe.argtypes = [ctypes.POINTER(PackItem), i, vp, ctypes.POINTER(i)]
+        L.gtts_pack_batch.argtypes = [vp, i, i, vp]
         L.gtts_ubench_mfma_out_floats.argtypes = [i]
         L.gtts_ubench_mfma_out_floats.restype = sz
         L.gtts_ubench_mfma.argtypes = [vp, sz, vp, i, i, ctypes.POINTER(ctypes.c_double), vp]
@@ -919,6 +928,7 @@ def clear_packed_cache():
     global _PACK_GEN
     _PACK_GEN += 1
     _PACKED.clear()
+    _PACK_PLANS.clear()
 
 
 def _packed_weight(weight, cin, cout, transposed, kind):
@@ -953,6 +963,52 @@ def _packed_weight(weight, cin, cout, transposed, kind):
 
 def _packed_conv3x3(weight, cin, cout, transposed):
     return _packed_weight(weight, cin, cout, transposed, "3x3")
+
+
+_PACK_PLANS = {}       # signature of a spec list -> device descriptor table + the blobs it fills
+_KIND_CODE = {"3x3": 0, "1x1": 1, "dn": 2, "up": 3, "dn_T": 4}
+
+
+def prepack(specs):
+    """All weight packs of one training step in ONE launch (gtts_pack_batch).  specs: [(weight, cin, cout, transposed, kind)] with the
+    meanings of _packed_weight (cin / cout of the convolution being packed).  The blobs are allocated once per spec list and re-filled
+    in place at every call; the per-weight cache entries are stamped with the current pack generation, so the autograd Functions of
+    this step find them and nothing older survives.  Call after new_pack_generation(), on the stream the step runs on."""
+    if not specs:
+        return
+    L = lib()
+    dev = specs[0][0].device
+    sig = tuple((id(w), w.data_ptr(), int(ci), int(co), bool(t), k) for w, ci, co, t, k in specs)
+    plan = _PACK_PLANS.get(sig)
+    if plan is None or any(r() is None for r in plan["refs"]):
+        n = len(specs)
+        items = (PackItem * n)()
+        blobs = []
+        with _on(dev):
+            for k, (w, ci, co, t, kind) in enumerate(specs):
+                if kind == "3x3":
+                    nb = L.gtts_conv3x3_packed_bytes(int(ci), int(co))
+                elif kind == "1x1":
+                    nb = L.gtts_conv1x1_packed_bytes(int(ci), int(co))
+                else:
+                    nb = L.gtts_conv_resample_packed_bytes(int(ci), int(co), 0 if kind == "dn" else 1)
+                blob = torch.empty(int(nb), dtype=torch.uint8, device=dev)
+                blobs.append(blob)
+                items[k].w, items[k].packed = w.data_ptr(), blob.data_ptr()
+                items[k].kind, items[k].cin, items[k].cout, items[k].transposed = _KIND_CODE[kind], int(ci), int(co), 1 if t else 0
+            nbytes = int(L.gtts_pack_batch_desc_bytes(n))
+            host = (ctypes.c_ubyte * nbytes)()
+            grid = ctypes.c_int(0)
+            _check(L.gtts_pack_batch_describe(items, n, ctypes.cast(host, ctypes.c_void_p), ctypes.byref(grid)), "gtts_pack_batch_describe")
+            desc = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev)
+        plan = {"desc": desc, "n": n, "grid": int(grid.value), "blobs": blobs, "refs": [weakref.ref(w) for w, *_ in specs]}
+        if len(_PACK_PLANS) >= 8:
+            _PACK_PLANS.clear()
+        _PACK_PLANS[sig] = plan
+    with _on(dev):
+        _check(L.gtts_pack_batch(_ptr(plan["desc"]), plan["n"], plan["grid"], _stream()), "gtts_pack_batch")
+    for (w, ci, co, t, kind), blob in zip(specs, plan["blobs"]):
+        _PACKED[(id(w), bool(t), kind)] = (weakref.ref(w), int(w._version), _PACK_GEN, blob)
 
 
 def _const(device, kind, *shape):

@@ -107,6 +107,15 @@ hipError_t launch_attn_fold(const float *ctxn, const float *wq, const float *wou
 
 // ---- pack.hip
 hipError_t launch_pack_conv(int mode, const float *w, unsigned char *dst, int cin, int cout, hipStream_t st);
+// one descriptor per convolution of a batched pack (device-resident table; 64 bytes)
+struct PackDesc {
+    const float *w;
+    void *dst;
+    size_t total;            // (hi, lo) element pairs
+    int mode, cin, cout, MT, nst, tps, nchunk, ncot, nkg, pad_;
+};
+void pack_describe(int mode, const float *w, void *dst, int cin, int cout, PackDesc *out);
+hipError_t launch_pack_batch(const PackDesc *descs_dev, int n, int grid_x, hipStream_t st);
 hipError_t launch_pack_attn_kv(const float *wqkv, unsigned char *dst, int C, hipStream_t st);
 hipError_t launch_copy_f32(const float *src, float *dst, size_t n, hipStream_t st);
 

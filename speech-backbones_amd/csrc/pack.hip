@@ -11,10 +11,9 @@
 
 namespace gtts {
 
-__global__ void pack_conv_kernel(const float *__restrict__ w, __bf16 *__restrict__ dst, int mode, int cin, int cout,
-                                 int MT, int nst, int tps, int nchunk, int ncot, int nkg, size_t total) {
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;   // one thread per (hi, lo) element pair
-    if (t >= total) return;
+// one (hi, lo) element pair t of one convolution's packed blob
+__device__ __forceinline__ void pack_conv_element(const float *__restrict__ w, __bf16 *__restrict__ dst, int mode, int cin, int cout,
+                                                  int MT, int nst, int tps, int nchunk, int ncot, int nkg, size_t t) {
     // decode t -> (phase, chunk, stage, cot, tap, kg, m, i)
     size_t r = t;
     const int i = r % 8; r /= 8;
@@ -44,7 +43,10 @@ __global__ void pack_conv_kernel(const float *__restrict__ w, __bf16 *__restrict
             const int py = phase >> 1, px = phase & 1;
             const int ky = py == 0 ? (stage == 0 ? 1 : 3) : (stage == 0 ? 0 : 2);
             const int kx = px == 0 ? (tap == 0 ? 1 : 3) : (tap == 0 ? 0 : 2);
-            v = w[(((size_t)ci * cout + co) * 4 + ky) * 4 + kx];
+            if (mode == CONV_UP + 16)      // Downsample's data gradient: its 3x3 forward weight [ci][co][3][3] read as a zero-padded 4x4 kernel
+                v = (ky < 3 && kx < 3) ? w[(((size_t)ci * cout + co) * 3 + ky) * 3 + kx] : 0.f;
+            else
+                v = w[(((size_t)ci * cout + co) * 4 + ky) * 4 + kx];
         }
     }
     __bf16 hi, lo;
@@ -57,16 +59,51 @@ __global__ void pack_conv_kernel(const float *__restrict__ w, __bf16 *__restrict
     dst[e_lo] = lo;
 }
 
+__global__ void pack_conv_kernel(const float *__restrict__ w, __bf16 *__restrict__ dst, int mode, int cin, int cout,
+                                 int MT, int nst, int tps, int nchunk, int ncot, int nkg, size_t total) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;   // one thread per (hi, lo) element pair
+    if (t >= total) return;
+    pack_conv_element(w, dst, mode, cin, cout, MT, nst, tps, nchunk, ncot, nkg, t);
+}
+
+// All convolution weights of a training step in ONE launch (blockIdx.y = weight): the packs of a step live for that step only
+// (the weights change with every optimizer step), and ~90 separate 5-us pack launches were 0.4 ms of a 12 ms step.
+__global__ void pack_conv_batch_kernel(const PackDesc *__restrict__ descs) {
+    const PackDesc d = descs[blockIdx.y];
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < d.total; t += (size_t)gridDim.x * 256)
+        pack_conv_element(d.w, reinterpret_cast<__bf16 *>(d.dst), d.mode, d.cin, d.cout, d.MT, d.nst, d.tps, d.nchunk, d.ncot, d.nkg, t);
+}
+
+static void pack_geometry(int mode, int cin, int cout, PackDesc &d) {
+    ConvGeom g = conv_geom(mode & 15, cin, cout);
+    d.mode = mode; d.cin = cin; d.cout = cout;
+    d.nkg = 2 * g.kch;
+    d.nchunk = (cin + 8 * d.nkg - 1) / (8 * d.nkg);
+    d.ncot = (cout + g.MT - 1) / g.MT;
+    d.MT = g.MT; d.nst = g.nst; d.tps = g.tps;
+    const int phases = (mode & 15) == CONV_UP ? 4 : 1;
+    d.total = (size_t)phases * d.nchunk * g.nst * d.ncot * g.tps * d.nkg * g.MT * 8;
+}
+
+void pack_describe(int mode, const float *w, void *dst, int cin, int cout, PackDesc *out) {
+    pack_geometry(mode, cin, cout, *out);
+    out->w = w;
+    out->dst = dst;
+}
+
+hipError_t launch_pack_batch(const PackDesc *descs_dev, int n, int grid_x, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_conv_batch_kernel, dim3((unsigned)grid_x, (unsigned)n), dim3(256), 0, st, descs_dev);
+    return hipGetLastError();
+}
+
 // mode CONV_C3 + 16 / CONV_P1 + 16: the transposed (and, 3x3, flipped) packing of a conv for its data gradient (cin, cout are
 // those of the gradient convolution, i.e. swapped with respect to the forward weight tensor)
 hipError_t launch_pack_conv(int mode, const float *w, unsigned char *dst, int cin, int cout, hipStream_t st) {
-    ConvGeom g = conv_geom(mode & 15, cin, cout);
-    const int nkg = 2 * g.kch;
-    const int nchunk = (cin + 8 * nkg - 1) / (8 * nkg), ncot = (cout + g.MT - 1) / g.MT;
-    const int phases = (mode & 15) == CONV_UP ? 4 : 1;
-    const size_t total = (size_t)phases * nchunk * g.nst * ncot * g.tps * nkg * g.MT * 8;
-    hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w,
-                       reinterpret_cast<__bf16 *>(dst), mode, cin, cout, g.MT, g.nst, g.tps, nchunk, ncot, nkg, total);
+    PackDesc d;
+    pack_geometry(mode, cin, cout, d);
+    hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((d.total + 255) / 256)), dim3(256), 0, st, w,
+                       reinterpret_cast<__bf16 *>(dst), mode, cin, cout, d.MT, d.nst, d.tps, d.nchunk, d.ncot, d.nkg, d.total);
     return hipGetLastError();
 }
 

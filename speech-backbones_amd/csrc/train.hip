@@ -331,6 +331,44 @@ extern "C" int gtts_conv_resample_pack(const float *w, void *packed, int cin, in
     return GTTS_OK;
 }
 
+// ---- all weight packs of a training step in one launch (ABI 4) ----------------------------------------------------------
+// gtts_pack_batch_describe fills `desc_host` (gtts_pack_batch_desc_bytes(n) bytes of HOST memory) with one launch descriptor per
+// item; the caller copies the table to the device once (the weight and blob addresses of a module do not change between steps)
+// and calls gtts_pack_batch(desc_dev, n, grid_x) at the top of every step: one launch, graph-capturable, no host work.
+extern "C" size_t gtts_pack_batch_desc_bytes(int n) { return n > 0 ? (size_t)n * sizeof(PackDesc) : 0; }
+
+extern "C" int gtts_pack_batch_describe(const gtts_pack_item *items, int n, void *desc_host, int *grid_x) {
+    if (!items || !desc_host || !grid_x) return tfail(GTTS_E_NULL, "gtts_pack_batch_describe: null argument");
+    if (n <= 0) return tfail(GTTS_E_SHAPE, "gtts_pack_batch_describe: n must be positive");
+    PackDesc *d = reinterpret_cast<PackDesc *>(desc_host);
+    size_t mx = 0;
+    for (int k = 0; k < n; ++k) {
+        const gtts_pack_item &it = items[k];
+        if (!it.w || !it.packed || it.cin <= 0 || it.cout <= 0) return tfail(GTTS_E_SHAPE, "gtts_pack_batch_describe: bad item %d", k);
+        int mode;
+        switch (it.kind) {
+            case 0: mode = it.transposed ? CONV_C3 + 16 : CONV_C3; break;
+            case 1: mode = it.transposed ? CONV_P1 + 16 : CONV_P1; break;
+            case 2: mode = CONV_DN; break;
+            case 3: mode = CONV_UP; break;
+            case 4: mode = CONV_UP + 16; break;       // Downsample's data gradient: the 3x3 forward weight as a zero-padded 4x4 transposed conv
+            default: return tfail(GTTS_E_SHAPE, "gtts_pack_batch_describe: unknown kind %d", it.kind);
+        }
+        memset(&d[k], 0, sizeof(PackDesc));
+        pack_describe(mode, it.w, it.packed, it.cin, it.cout, &d[k]);
+        mx = std::max(mx, d[k].total);
+    }
+    *grid_x = (int)std::min<size_t>(std::max<size_t>((mx + 1023) / 1024, 1), 256);       // ~4 element pairs per thread on the largest weight
+    return GTTS_OK;
+}
+
+extern "C" int gtts_pack_batch(const void *desc_dev, int n, int grid_x, gtts_stream_t stream) {
+    if (!desc_dev) return tfail(GTTS_E_NULL, "gtts_pack_batch: null argument");
+    if (n <= 0 || grid_x <= 0) return tfail(GTTS_E_SHAPE, "gtts_pack_batch: bad sizes");
+    TCHK(launch_pack_batch(reinterpret_cast<const PackDesc *>(desc_dev), n, grid_x, (hipStream_t)stream));
+    return GTTS_OK;
+}
+
 // y = conv(x * mask) + bias; x [B,cin,H,W], mask [B,W] (columns of the INPUT).  H and W even for up = 0.
 extern "C" int gtts_conv_resample(const float *x, const float *mask, const void *packed, const float *bias, float *y, int B, int cin,
                                   int cout, int H, int W, int up, gtts_stream_t stream) {

@@ -366,9 +366,40 @@ def time_embedding(est, t):
     return F.linear(_mish(F.linear(emb, l0.weight, l0.bias)), l2.weight, l2.bias)
 
 
+def _pack_specs(est):
+    """Every convolution weight the HIP training kernels of one step multiply with, in the forms they need (forward packing and,
+    where a data gradient is taken, the transposed one): the argument of backend().prepack.  First layers (2 / 3 stacked input
+    planes) and Upsample's re-indexed gradient weight pack themselves where they are used."""
+    be = backend()
+    specs = []
+    for mod in est.modules():
+        if isinstance(mod, torch.nn.ConvTranspose2d):
+            ci, co = mod.in_channels, mod.out_channels
+            if mod.kernel_size == (4, 4) and be.resample_supported(ci, co, 2, 2, True):
+                specs.append((mod.weight, ci, co, False, "up"))
+        elif isinstance(mod, torch.nn.Conv2d):
+            ci, co = mod.in_channels, mod.out_channels
+            if mod.kernel_size == (3, 3) and mod.stride == (2, 2):
+                if be.resample_supported(ci, co, 2, 2, False):
+                    specs.append((mod.weight, ci, co, False, "dn"))
+                    specs.append((mod.weight, co, ci, False, "dn_T"))
+            elif mod.kernel_size == (3, 3) and mod.stride == (1, 1) and ci >= 16:
+                if be.conv3x3_supported(ci, co, need_dgrad=True):
+                    specs.append((mod.weight, ci, co, False, "3x3"))
+                    specs.append((mod.weight, co, ci, True, "3x3"))
+            elif mod.kernel_size == (1, 1) and ci >= 16:
+                if be.conv1x1_supported(ci, co, need_dgrad=True):
+                    specs.append((mod.weight, ci, co, False, "1x1"))
+                    specs.append((mod.weight, co, ci, True, "1x1"))
+    return specs
+
+
 def estimator(est, x, mask, mu, t, spk=None):
     if not FORCE_TORCH and x.is_cuda:
-        backend().new_pack_generation()        # packed weight copies live for this call's forward + backward only
+        be = backend()
+        be.new_pack_generation()               # packed weight copies live for this call's forward + backward only ...
+        if torch.is_grad_enabled():
+            be.prepack(_pack_specs(est))       # ... and all of them are made here, in one launch
     temb = time_embedding(est, t)
     planes = [mu, x]
     if est.n_spks >= 2:
