@@ -213,6 +213,25 @@ def test_vc_ml_n30_free_running_dim64(S, dev):
     assert e <= 2 * REL
 
 
+def test_vc_ml_n30_free_running_dim256(S, dev):
+    """The published decoder width at the notebook's own N, all 30 steps free-running (round 3 had this teacher-forced only):
+    T = 128 keeps the 117.8 M-parameter CPU oracle to well under a minute."""
+    sd = V.make_state(dim_base=256, seed=6)
+    plan = S.Plan(dim=256, arch=1)
+    blob = plan.pack(sd, dev)
+    inp = V.make_inputs(1, 128, 40, seed=31)
+    g = torch.Generator().manual_seed(19)
+    noise = torch.randn(30, 1, 80, 128, generator=g)
+    ref = V.reverse_diffusion(sd, inp["z"], inp["mask"], inp["mean"], inp["ref"], inp["ref_mask"], inp["mean_ref"], inp["c"], 30,
+                              "ml", noise=noise)
+    a = {k: v.to(dev) for k, v in inp.items()}
+    out = plan.vc_reverse_diffusion(blob, a["z"], a["mask"], a["mean"], a["ref"], a["ref_mask"], a["mean_ref"], a["c"], 30, "ml",
+                                    noise=noise.to(dev)).cpu()
+    e = relerr(out, ref)
+    print("DiffVC ml N=30 dim256 free-running: rel err %.2e" % e)
+    assert e <= 2 * REL
+
+
 def test_diffvc_model_shell_drop_in(S, dev):
     """`from model import DiffVC` (DiffVC/inference.ipynb): the whole model shell on the GPU -- MelEncoder, PostNet and the
     decoder's sampler through the C ABI -- against the same composition of the CPU oracles."""
