@@ -36,8 +36,11 @@
 #ifndef GTTS_C3_WAVES_BF16
 #define GTTS_C3_WAVES_BF16 3
 #endif
-#define GTTS_WAVES(MODE) ((MODE) == CONV_DN ? 2 : GTTS_C3_WAVES)
-#define GTTS_WAVES_NS(MODE, NSPLIT) ((MODE) == CONV_DN ? 2 : ((NSPLIT) == 1 ? GTTS_C3_WAVES_BF16 : GTTS_C3_WAVES))
+#ifndef GTTS_DN_WAVES
+#define GTTS_DN_WAVES 2
+#endif
+#define GTTS_WAVES(MODE) ((MODE) == CONV_DN ? GTTS_DN_WAVES : GTTS_C3_WAVES)
+#define GTTS_WAVES_NS(MODE, NSPLIT) ((MODE) == CONV_DN ? GTTS_DN_WAVES : ((NSPLIT) == 1 ? GTTS_C3_WAVES_BF16 : GTTS_C3_WAVES))
 // Diagnostics exist only in -DGTTS_DIAG builds (tools/abexp.sh, tools/trace_conv.py); the product library is compiled
 // without it and the three switches below are then forced off, whatever else is on the command line.
 // GTTS_EXP: timing-only ablations of the main loop (results are WRONG)
