@@ -57,10 +57,161 @@ __global__ __launch_bounds__(256) void mas_kernel(const float *__restrict__ valu
     }
 }
 
+// ---- round 4: one DP wave per sample, columns staged through LDS ------------------------------------------------------------
+// The kernel above pays one workgroup barrier and one round trip of stride-t_y (uncoalesced) global loads per column, and its
+// backtrack is 1 k dependent global loads by one thread: 0.8 ms for 16 x 200 x 1024.  Here:
+//   * waves 1-3 stage tiles of TY columns (coalesced 128-byte row segments, value * mask applied) transposed into LDS, one tile ahead;
+//   * wave 0 owns the whole column: lane l holds rows l*R .. l*R+R-1 of the previous column in registers (row x-1 of its first row
+//     comes from lane l-1 by one shuffle), so a DP step is R LDS reads + R max/add, no barrier (one barrier per TILE);
+//   * the backtrack predicates of a column are R bits per lane: one coalesced 128-byte store per column ([b][t_y][64] u16 in the
+//     caller's scratch), read back through LDS in chunks for the backtrack, which walks them with LDS-latency dependent reads.
+// Same arithmetic per cell as the reference (one fp32 max, one fp32 add, strict '<'): bit-identical paths.
+template <int R, int TY>
+__global__ __launch_bounds__(256) void mas_wave_kernel(const float *__restrict__ value, const float *__restrict__ mask,
+                                                       const int *__restrict__ t_xs, const int *__restrict__ t_ys,
+                                                       int *__restrict__ path, unsigned short *__restrict__ flags, int tx, int ty) {
+    constexpr int TXP = 64 * R + 4;                    // row pitch of a staged column (a multiple of 4 floats: a lane's R rows are 16-byte reads)
+    constexpr int CH = 256;                            // columns per backtrack chunk (CH * 64 u16 = 32 KB, inside the tile buffers)
+    static_assert(2 * TY * TXP * 4 >= CH * 64 * 2, "the backtrack chunk reuses the tile buffers");
+    extern __shared__ float sm[];                      // [2][TY][TXP]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t_x = t_xs[b], t_y = t_ys[b];
+    if (t_x <= 0 || t_y <= 0 || t_x > tx || t_y > ty) return;   // reference behaviour undefined: all-zero path
+    const float NEG = -1e9f;
+    const size_t base = (size_t)b * tx * ty;
+    const float *val = value + base;
+    const float *msk = mask ? mask + base : nullptr;
+    unsigned short *flg = flags + (size_t)b * ty * 64;
+    const int ntile = (t_y + TY - 1) / TY;
+
+    // stage tile t into buffer t & 1: lane -> (row parity group, column), TY columns per row segment
+    auto stage = [&](int t, int first_wave, int nwaves) {
+        float *dst = sm + (size_t)(t & 1) * TY * TXP;
+        const int y0 = t * TY;
+        constexpr int RPI = 64 / TY;                   // rows per wave instruction
+        constexpr int U = 8;                           // row groups in flight per lane (a tile is latency-, not bandwidth-bound)
+        const int col = lane % TY, sub = lane / TY;
+        const int y = y0 + col;
+        const bool yok = y < t_y;
+        const int step = nwaves * RPI;
+        for (int xb = (wave - first_wave) * RPI + sub; xb < t_x; xb += step * U) {
+            float v[U], m[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int x = min(xb + u * step, t_x - 1);                      // (clamped: the extra loads are not stored)
+                const size_t o = (size_t)x * ty + (yok ? y : 0);
+                v[u] = val[o];
+                m[u] = msk ? msk[o] : 1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int x = xb + u * step;
+                if (x < t_x) dst[col * TXP + x] = yok ? (msk ? __fmul_rn(v[u], m[u]) : v[u]) : 0.f;     // value * mask (__init__.py:13)
+            }
+        }
+    };
+    stage(0, 0, 4);
+    __syncthreads();
+    float prevv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) prevv[r] = NEG;
+    const int x0 = lane * R;
+    for (int t = 0; t < ntile; ++t) {
+        if (wave != 0) {
+            if (t + 1 < ntile) stage(t + 1, 1, 3);
+        } else {
+            const float *src = sm + (size_t)(t & 1) * TY * TXP;
+            const int y0 = t * TY, yn = min(TY, t_y - y0);
+            typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+            f32x4_t vin[R / 4], vnext[R / 4];
+#pragma unroll
+            for (int q = 0; q < R / 4; ++q) vnext[q] = *reinterpret_cast<const f32x4_t *>(src + x0 + 4 * q);
+            for (int j = 0; j < yn; ++j) {
+                const int y = y0 + j;
+                const int lo = max(0, t_x + y - t_y), hi = min(t_x, y + 1);
+                const unsigned span = (unsigned)(hi - lo);
+#pragma unroll
+                for (int q = 0; q < R / 4; ++q) vin[q] = vnext[q];
+                if (j + 1 < yn) {                                                 // next column's rows: in flight during this step's arithmetic
+#pragma unroll
+                    for (int q = 0; q < R / 4; ++q) vnext[q] = *reinterpret_cast<const f32x4_t *>(src + (j + 1) * TXP + x0 + 4 * q);
+                }
+                // value[x0-1][y-1]: the last row of lane l-1 (DPP wave shift, no LDS round trip); lane 0 has no row above: the
+                // reference's 0 (first column) / max_neg (core.pyx:22-26)
+                float left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, prevv[R - 1]), 0x138, 0xf, 0xf, false));
+                if (lane == 0) left = y == 0 ? 0.f : NEG;
+                float nv[R];
+                unsigned bits = 0;
+                const unsigned xrel = (unsigned)(x0 - lo);                        // row x is inside the band iff xrel + r < span (unsigned)
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float pm1 = r == 0 ? left : prevv[r - 1];               // value[x-1][y-1] (core.pyx:22-28)
+                    // value[x][y-1] (core.pyx:18-21): the diagonal cell x == y was outside the previous column's band, and cells
+                    // outside the band hold max_neg here -- the reference's `if x == y: v_cur = max_neg` without a compare
+                    const float pc = prevv[r];
+                    const float mx = fmaxf(pc, pm1);                              // (pc > pp ? pc : pp: no NaNs, no signed zeros that matter)
+                    const float sum = __fadd_rn(mx, vin[r / 4][r % 4]);           // core.pyx:30 (computed for every lane: branch-free)
+                    const bool in = xrel + (unsigned)r < span;
+                    nv[r] = in ? sum : NEG;
+                    // backtrack predicate (:34).  Bits of cells with x == 0, x == y or y == 0 are never consulted (the backtrack
+                    // tests index != 0, index == y and y > 0 itself)
+                    const bool lt = pc < pm1;
+                    bits |= (unsigned)(in & lt) << r;
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) prevv[r] = nv[r];
+                flg[(size_t)y * 64 + lane] = (unsigned short)bits;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- backtrack (core.pyx:32-35) in chunks of CH columns staged into LDS
+    __threadfence_block();
+    unsigned short *s_f = reinterpret_cast<unsigned short *>(sm);
+    int index = t_x - 1;
+    for (int c1 = t_y; c1 > 0; c1 -= CH) {
+        const int c0 = max(0, c1 - CH);
+        __syncthreads();
+        for (int i = tid; i < (c1 - c0) * 64; i += 256) s_f[i] = flg[(size_t)c0 * 64 + i];
+        __syncthreads();
+        if (tid == 0) {
+            for (int y = c1 - 1; y >= c0; --y) {
+                path[base + (size_t)index * ty + y] = 1;
+                if (index != 0) {
+                    const unsigned w = s_f[(y - c0) * 64 + index / R];
+                    if (index == y || (y > 0 && ((w >> (index % R)) & 1u))) index -= 1;
+                }
+            }
+        }
+    }
+}
+
+template <int R, int TY>
+static hipError_t launch_mas_wave(const float *value, const float *mask, const int *t_x, const int *t_y, int *path,
+                                  unsigned char *scratch, int b, int tx, int ty, hipStream_t st) {
+    const size_t smem = (size_t)2 * TY * (64 * R + 4) * sizeof(float);
+    static bool attr_done[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mas_wave_kernel<R, TY>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL((mas_wave_kernel<R, TY>), dim3(b), dim3(256), smem, st, value, mask, t_x, t_y, path,
+                       reinterpret_cast<unsigned short *>(scratch), tx, ty);
+    return hipGetLastError();
+}
+
 hipError_t launch_mas(const float *value, const float *mask, const int *t_x, const int *t_y, int *path,
                       unsigned char *scratch, int b, int tx, int ty, hipStream_t st) {
     hipError_t e = hipMemsetAsync(path, 0, (size_t)b * tx * ty * sizeof(int), st);
     if (e != hipSuccess) return e;
+    if (tx <= 256) return launch_mas_wave<4, 32>(value, mask, t_x, t_y, path, scratch, b, tx, ty, st);
+    if (tx <= 512) return launch_mas_wave<8, 32>(value, mask, t_x, t_y, path, scratch, b, tx, ty, st);
+    if (tx <= 1024) return launch_mas_wave<16, 16>(value, mask, t_x, t_y, path, scratch, b, tx, ty, st);
     const size_t smem = (size_t)2 * tx * sizeof(float);
     if (smem > 160 * 1024) return hipErrorInvalidValue;
     if (smem > 48 * 1024) {

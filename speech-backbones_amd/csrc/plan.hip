@@ -1280,7 +1280,8 @@ extern "C" int gtts_vc_reverse_diffusion(gtts_plan *plan, const void *packed, co
 
 extern "C" size_t gtts_mas_scratch_bytes(int b, int tx, int ty) {
     if (b <= 0 || tx <= 0 || ty <= 0) return 0;
-    return (size_t)b * tx * ty;
+    // one byte per cell (column-sweep kernel, t_x > 1024) or 64 x u16 per column (one-wave kernel): the larger of the two
+    return std::max((size_t)b * tx * ty, (size_t)b * ty * 128);
 }
 
 extern "C" int gtts_mas_maximum_path(const float *value, const float *mask, const int *t_x, const int *t_y, int *path,

@@ -85,7 +85,10 @@ def test_mas_golden_bit_exact(S, dev):
     assert torch.equal(path.to(torch.uint8), _t(g["path"]))
 
 
-@pytest.mark.parametrize("b,tx,ty", [(4, 31, 90), (3, 1, 7), (2, 50, 50), (6, 13, 200), (16, 200, 1024), (2, 300, 1000)])
+# (t_x <= 256 / 512 / 1024 take the one-wave kernel with 4 / 8 / 16 rows per lane, larger t_x the column-sweep kernel; 255-257 and
+# 1024-1025 sit on the switch-overs, t_y = 33 / 257 on the tile and backtrack-chunk edges)
+@pytest.mark.parametrize("b,tx,ty", [(4, 31, 90), (3, 1, 7), (2, 50, 50), (6, 13, 200), (16, 200, 1024), (2, 300, 1000),
+                                     (2, 256, 300), (2, 257, 257), (2, 700, 900), (1, 1024, 1100), (1, 1025, 1100), (3, 20, 33)])
 def test_mas_random_ragged_bit_exact(S, dev, b, tx, ty):
     g = torch.Generator().manual_seed(b * 1000 + tx)
     value = torch.randn(b, tx, ty, generator=g) * 4
