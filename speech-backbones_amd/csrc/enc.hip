@@ -153,6 +153,151 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const float *__restr
     }
 }
 
+// ---- round 4: the same attention with LANES ALONG THE KEYS (coalesced K / V reads) and 16 queries per workgroup.
+// The kernel above reads a K element once per query (8 x per workgroup) and walks V with one row per lane (each lane its own
+// cache line): 2.1 ms per call for the DiffVC MelEncoder at L = 1024, B = 16 -- half of the average-voice encoder.  Here a K or V
+// element is loaded once per workgroup and used for all 16 queries:
+//   scores   lane = key j, 16 accumulators (one per query), the 16 query values of channel d as four broadcast 16-byte LDS reads;
+//   softmax  one wave per four query rows (unchanged arithmetic: max, exp, sum, scale);
+//   output   lane = key j again: four channels x 16 queries of accumulators per pass, wave sums at the end, relative-value terms
+//            added by the 16 lanes that store.
+// Same formulas and the same fp32 operation order per element as above up to the association of the two long sums.
+constexpr int ATT16_QT = 16;
+static inline size_t att16_smem_bytes(int dk, int L) {
+    const int LP = (L + 63) / 64 * 64;
+    return ((size_t)dk * ATT16_QT + ATT16_QT * 16 + (size_t)ATT16_QT * LP + 4 * 64) * sizeof(float);
+}
+__global__ __launch_bounds__(256) void enc_attention16_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                              const float *__restrict__ v, const float *__restrict__ mask,
+                                                              const float *__restrict__ ek, const float *__restrict__ ev,
+                                                              float *__restrict__ out, int C, int L, int heads, int win) {
+    constexpr int QT = ATT16_QT;
+    extern __shared__ float sm[];
+    const int dk = C / heads, LP = (L + 63) / 64 * 64;
+    float *s_q = sm;                         // [dk][QT]
+    float *s_rel = s_q + dk * QT;            // [QT][16]: q_i . Ek[r]
+    float *s_p = s_rel + QT * 16;            // [QT][LP] scores, then probabilities
+    float *s_o = s_p + (size_t)QT * LP;      // [4 waves][4 dd x 16 q]: totals of one output pass
+    const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * QT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t hb = ((size_t)b * C + (size_t)h * dk) * L;
+    const float *qb = q + hb, *kb = k + hb, *vb = v + hb, *mb = mask + (size_t)b * L;
+    const float inv = 1.0f / sqrtf((float)dk);
+    const int nr = win >= 0 ? 2 * win + 1 : 0;
+    for (int e = tid; e < QT * dk; e += 256) {
+        const int d = e / QT, qi = e - d * QT;
+        s_q[e] = i0 + qi < L ? qb[(size_t)d * L + i0 + qi] : 0.f;
+    }
+    __syncthreads();
+    for (int e = tid; e < QT * nr; e += 256) {
+        const int qi = e / nr, r = e - qi * nr;
+        float ar = 0.f;
+        for (int d = 0; d < dk; ++d) ar = fmaf(s_q[d * QT + qi], ek[r * dk + d], ar);
+        s_rel[qi * 16 + r] = ar;
+    }
+    __syncthreads();
+    const int nblk = LP / 64;
+    // ---- scores
+    for (int jb = wave; jb < nblk; jb += 4) {
+        const int j = jb * 64 + lane;
+        const bool valid = j < L;
+        const int jc = valid ? j : L - 1;
+        float acc[QT];
+#pragma unroll
+        for (int qi = 0; qi < QT; ++qi) acc[qi] = 0.f;
+        for (int d = 0; d < dk; ++d) {
+            const float kv = kb[(size_t)d * L + jc];
+            const float4 *q4 = reinterpret_cast<const float4 *>(s_q + d * QT);
+#pragma unroll
+            for (int g = 0; g < QT / 4; ++g) {
+                const float4 qq = q4[g];
+                acc[4 * g + 0] = fmaf(qq.x, kv, acc[4 * g + 0]);
+                acc[4 * g + 1] = fmaf(qq.y, kv, acc[4 * g + 1]);
+                acc[4 * g + 2] = fmaf(qq.z, kv, acc[4 * g + 2]);
+                acc[4 * g + 3] = fmaf(qq.w, kv, acc[4 * g + 3]);
+            }
+        }
+        const float mj = mb[jc];
+#pragma unroll
+        for (int qi = 0; qi < QT; ++qi) {
+            const int i = i0 + qi;
+            float sc = acc[qi] * inv;
+            const int r = j - i + win;
+            if (win >= 0 && r >= 0 && r <= 2 * win) sc = sc + s_rel[qi * 16 + r] * inv;
+            const float mi = mb[min(i, L - 1)];
+            if (mi * mj == 0.f) sc = -1e4f;
+            if (valid) s_p[(size_t)qi * LP + j] = sc;
+        }
+    }
+    __syncthreads();
+    // ---- softmax over the keys, one wave per four query rows
+    for (int qq = 0; qq < QT / 4; ++qq) {
+        const int qi = wave * (QT / 4) + qq;
+        if (i0 + qi >= L) continue;                               // wave-uniform
+        float *pv = s_p + (size_t)qi * LP;
+        float mx = -INFINITY;
+        for (int j = lane; j < L; j += 64) mx = fmaxf(mx, pv[j]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int j = lane; j < L; j += 64) {
+            const float e = expf(pv[j] - mx);
+            pv[j] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        const float rs = 1.0f / sum;
+        for (int j = lane; j < L; j += 64) pv[j] *= rs;
+    }
+    __syncthreads();
+    // ---- out[d][i] = sum_j p[i][j] v[d][j] (+ relative values): four channels per pass and wave
+    float *so = s_o + wave * 64;
+    for (int dg = wave; dg * 4 < dk; dg += 4) {
+        float acc[4][QT];
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd)
+#pragma unroll
+            for (int qi = 0; qi < QT; ++qi) acc[dd][qi] = 0.f;
+        for (int jb = 0; jb < nblk; ++jb) {
+            const int j = jb * 64 + lane;
+            const bool valid = j < L;
+            const int jc = valid ? j : L - 1;
+            float vv[4], pp[QT];
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                const int d = min(dg * 4 + dd, dk - 1);
+                vv[dd] = valid ? vb[(size_t)d * L + jc] : 0.f;
+            }
+#pragma unroll
+            for (int qi = 0; qi < QT; ++qi) pp[qi] = valid ? s_p[(size_t)qi * LP + j] : 0.f;
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd)
+#pragma unroll
+                for (int qi = 0; qi < QT; ++qi) acc[dd][qi] = fmaf(pp[qi], vv[dd], acc[dd][qi]);
+        }
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd)
+#pragma unroll
+            for (int qi = 0; qi < QT; ++qi) {
+                const float tot = wave_sum(acc[dd][qi]);
+                if (lane == dd * QT + qi) so[lane] = tot;
+            }
+        // (one wave: the LDS writes above are ordered before the reads below by the wave's own program order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        const int dd = lane / QT, qi = lane % QT;
+        const int d = dg * 4 + dd, i = i0 + qi;
+        if (d < dk && i < L) {
+            float o = so[lane];
+            const float *pv = s_p + (size_t)qi * LP;
+            for (int r = 0; r < nr; ++r) {
+                const int j = i + r - win;
+                if (j >= 0 && j < L) o = fmaf(pv[j], ev[r * dk + d], o);
+            }
+            out[hb + (size_t)d * L + i] = o;
+        }
+    }
+}
+
 }  // namespace gtts
 
 using namespace gtts;
@@ -388,10 +533,18 @@ extern "C" int gtts_enc_forward(const gtts_enc *e, const void *packed, const lon
         if ((rc = enc_conv(r, p + "conv_v", x, V, true, false, nullptr, false))) return rc;
         const float *ek = bp(r, p + "emb_rel_k"), *ev = bp(r, p + "emb_rel_v");
         const int win = cf.window_size > 0 ? cf.window_size : -1;
-        const size_t smem = (size_t)(ATT_QT * dk + ATT_QT * L) * 4;
-        ECHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&enc_attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(enc_attention_kernel, dim3((L + ATT_QT - 1) / ATT_QT, cf.n_heads, B), dim3(256), smem, st, Q, K, V, x_mask,
-                           ek, ev, A, C, L, cf.n_heads, win);
+        const size_t smem16 = att16_smem_bytes(dk, L);
+        if (smem16 <= (size_t)160 * 1024 && dk % 4 == 0 && win <= 7) {
+            // 16 queries per workgroup, lanes along the keys (two workgroups per CU up to L ~ 1000)
+            ECHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&enc_attention16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem16));
+            hipLaunchKernelGGL(enc_attention16_kernel, dim3((L + ATT16_QT - 1) / ATT16_QT, cf.n_heads, B), dim3(256), smem16, st, Q, K, V,
+                               x_mask, ek, ev, A, C, L, cf.n_heads, win);
+        } else {
+            const size_t smem = (size_t)(ATT_QT * dk + ATT_QT * L) * 4;
+            ECHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&enc_attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL(enc_attention_kernel, dim3((L + ATT_QT - 1) / ATT_QT, cf.n_heads, B), dim3(256), smem, st, Q, K, V, x_mask,
+                               ek, ev, A, C, L, cf.n_heads, win);
+        }
         ECHK(hipGetLastError());
         if ((rc = enc_conv(r, p + "conv_o", A, Z, false, false, nullptr, false))) return rc;
         snprintf(nm, sizeof nm, "encoder.norm_layers_1.%d", i);
