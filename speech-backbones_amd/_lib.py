@@ -978,9 +978,9 @@ def prepack(specs):
         return
     L = lib()
     dev = specs[0][0].device
-    sig = tuple((id(w), w.data_ptr(), int(ci), int(co), bool(t), k) for w, ci, co, t, k in specs)
-    plan = _PACK_PLANS.get(sig)
-    if plan is None or any(r() is None for r in plan["refs"]):
+    sig = tuple([w.data_ptr() for w, *_ in specs])          # (cheap per-step check: the addresses the descriptor table holds)
+    plan = _PACK_PLANS.get(id(specs))
+    if plan is None or plan["sig"] != sig or plan["specs"] is not specs:
         n = len(specs)
         items = (PackItem * n)()
         blobs = []
@@ -1001,14 +1001,17 @@ def prepack(specs):
             grid = ctypes.c_int(0)
             _check(L.gtts_pack_batch_describe(items, n, ctypes.cast(host, ctypes.c_void_p), ctypes.byref(grid)), "gtts_pack_batch_describe")
             desc = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev)
-        plan = {"desc": desc, "n": n, "grid": int(grid.value), "blobs": blobs, "refs": [weakref.ref(w) for w, *_ in specs]}
+        # (the plan keeps the spec list alive: its id is the cache key; weights are referenced weakly through the per-weight entries)
+        plan = {"desc": desc, "n": n, "grid": int(grid.value), "sig": sig, "specs": specs,
+                "entries": [((id(w), bool(t), kind), weakref.ref(w), w, blob) for (w, ci, co, t, kind), blob in zip(specs, blobs)]}
         if len(_PACK_PLANS) >= 8:
             _PACK_PLANS.clear()
-        _PACK_PLANS[sig] = plan
+        _PACK_PLANS[id(specs)] = plan
     with _on(dev):
         _check(L.gtts_pack_batch(_ptr(plan["desc"]), plan["n"], plan["grid"], _stream()), "gtts_pack_batch")
-    for (w, ci, co, t, kind), blob in zip(specs, plan["blobs"]):
-        _PACKED[(id(w), bool(t), kind)] = (weakref.ref(w), int(w._version), _PACK_GEN, blob)
+    gen = _PACK_GEN
+    for key, ref, w, blob in plan["entries"]:
+        _PACKED[key] = (ref, w._version, gen, blob)
 
 
 def _const(device, kind, *shape):

@@ -371,6 +371,9 @@ def _pack_specs(est):
     where a data gradient is taken, the transposed one): the argument of backend().prepack.  First layers (2 / 3 stacked input
     planes) and Upsample's re-indexed gradient weight pack themselves where they are used."""
     be = backend()
+    cached = est.__dict__.get("_gtts_pack_specs")
+    if cached is not None:
+        return cached                                     # (the module tree is static: built once per estimator object)
     specs = []
     for mod in est.modules():
         if isinstance(mod, torch.nn.ConvTranspose2d):
@@ -391,6 +394,7 @@ def _pack_specs(est):
                 if be.conv1x1_supported(ci, co, need_dgrad=True):
                     specs.append((mod.weight, ci, co, False, "1x1"))
                     specs.append((mod.weight, co, ci, True, "1x1"))
+    est.__dict__["_gtts_pack_specs"] = specs
     return specs
 
 
