@@ -40,17 +40,23 @@ struct C1Args {
 #ifndef GTTS_C1_WAVES128
 #define GTTS_C1_WAVES128 2
 #endif
-template <int WM, int WN, int MF, int TPS, int AITER>
+// KCH = 2 (three-tap layers with cin % 32 == 0 on the 128-row tile): a step of the channel loop stages 32 input channels and the
+// two packed 16-channel weight blocks that belong to them (the packing is unchanged), so the per-step costs that do not scale with
+// the MFMA work -- two barriers per weight stage, the exposed part of the activation round trip -- are paid half as often.  A k = 3
+// layer has only 36 MFMAs per wave and 16 channels: these layers were latency-bound (0.6 - 0.7 PFLOP/s executed at 2.2 TB/s).  The
+// MFMAs are issued in the order of two consecutive 16-channel steps: results are bit-identical to KCH = 1.
+template <int WM, int WN, int MF, int TPS, int AITER, int KCH = 1>
 __global__ __launch_bounds__(256, (WM * MF == 1) ? 4 : (WM * MF == 2 ? 3 : GTTS_C1_WAVES128)) void conv1d_mfma_kernel(const C1Args a) {
-    constexpr int MT = WM * MF * 32, NT = WN * 64, NKG = 2;
+    constexpr int MT = WM * MF * 32, NT = WN * 64, NKG = 2 * KCH;
     constexpr bool PF2 = MT >= 128;                             // activation prefetch distance 2 (else 1)
-    constexpr int WBLK16 = 2 * TPS * NKG * MT;                 // 16-byte units per weight stage (hi + lo)
-    constexpr int WITER = (WBLK16 + 255) / 256;
+    constexpr int WBLK16 = 2 * TPS * 2 * MT;                   // 16-byte units per packed 16-channel weight stage (hi + lo)
+    constexpr int WITER = (KCH * WBLK16 + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NPX = a.npx;
     u32x4 *s_ah = reinterpret_cast<u32x4 *>(smem);             // [NKG][NPX]
     u32x4 *s_al = s_ah + NKG * NPX;
-    u32x4 *s_w = s_al + NKG * NPX;                             // [split][tap][kg][MT]
+    u32x4 *s_w = s_al + NKG * NPX;                             // [KCH][split][tap][kg 2][MT]
+    const int nsteps = a.nchunk / KCH;                          // (the launcher picks KCH = 2 only for an even number of 16-channel chunks)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kgl = lane >> 5;
@@ -105,18 +111,19 @@ __global__ __launch_bounds__(256, (WM * MF == 1) ? 4 : (WM * MF == 2 ? 3 : GTTS_
         for (int it = 0; it < AITER; ++it)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(rsx, it_voff[it], (chunk * 16 + i) * a.Lin * 4, 0);
+                const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(rsx, it_voff[it], (chunk * 16 * KCH + i) * a.Lin * 4, 0);
                 araw[it][i] = __builtin_bit_cast(float, u);
             }
     };
     u32x4 wregs[WITER];
     const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(a.w);
     auto load_w = [&](int chunk, int stage) {
-        const size_t blk = ((size_t)chunk * a.nst + stage) * ncot + cot;
 #pragma unroll
         for (int i = 0; i < WITER; ++i) {
             const int u = tid + i * 256;
-            wregs[i] = wsrc[blk * WBLK16 + (u < WBLK16 ? u : 0)];
+            const int kc = KCH == 1 ? 0 : min(u / WBLK16, KCH - 1), ub = u - kc * WBLK16;      // packed block of 16-channel chunk chunk * KCH + kc
+            const size_t blk = ((size_t)(chunk * KCH + kc) * a.nst + stage) * ncot + cot;
+            wregs[i] = wsrc[blk * WBLK16 + (ub < WBLK16 ? ub : 0)];
         }
     };
 
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256, (WM * MF == 1) ? 4 : (WM * MF == 2 ? 3 : GTTS_
 
     load_w(0, 0);
     load_act(0, std::integral_constant<int, 0>{});
-    if (PF2 && a.nchunk > 1) load_act(1, std::integral_constant<int, 1>{});
+    if (PF2 && nsteps > 1) load_act(1, std::integral_constant<int, 1>{});
     const int m0 = wm * MF * 32;
     auto do_chunk = [&](int chunk, auto set_c) {
         constexpr int SET = PF2 ? decltype(set_c)::value : 0;
@@ -155,30 +162,32 @@ __global__ __launch_bounds__(256, (WM * MF == 1) ? 4 : (WM * MF == 2 ? 3 : GTTS_
                 s_al[idx] = *reinterpret_cast<u32x4 *>(&vl);
             }
         }
-        if (chunk + (PF2 ? 2 : 1) < a.nchunk) load_act(chunk + (PF2 ? 2 : 1), set_c);     // the set just consumed is free again
+        if (chunk + (PF2 ? 2 : 1) < nsteps) load_act(chunk + (PF2 ? 2 : 1), set_c);     // the set just consumed is free again
         for (int stage = 0; stage < a.nst; ++stage) {
             if (stage > 0) lds_barrier();                         // previous stage's MFMAs are done with s_w
 #pragma unroll
             for (int i = 0; i < WITER; ++i) {
                 const int u = tid + i * 256;
-                if (u < WBLK16) s_w[u] = wregs[i];
+                if (u < KCH * WBLK16) s_w[u] = wregs[i];
             }
             lds_barrier();
             if (stage + 1 < a.nst) load_w(chunk, stage + 1);
-            else if (chunk + 1 < a.nchunk) load_w(chunk + 1, 0);
+            else if (chunk + 1 < nsteps) load_w(chunk + 1, 0);
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc)
 #pragma unroll
             for (int j = 0; j < TPS; ++j) {
                 const int off = a.halo_lo + a.toff[stage * TPS + j] + wn * 64 + l31;
                 bf16x8 wh[MF], wl[MF], xh[2], xl[2];
 #pragma unroll
                 for (int mi = 0; mi < MF; ++mi) {
-                    const int wi = (j * NKG + kgl) * MT + m0 + mi * 32 + l31;
+                    const int wi = kc * WBLK16 + (j * 2 + kgl) * MT + m0 + mi * 32 + l31;
                     wh[mi] = *reinterpret_cast<const bf16x8 *>(&s_w[wi]);
-                    wl[mi] = *reinterpret_cast<const bf16x8 *>(&s_w[wi + TPS * NKG * MT]);
+                    wl[mi] = *reinterpret_cast<const bf16x8 *>(&s_w[wi + TPS * 2 * MT]);
                 }
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
-                    const int xi = kgl * NPX + off + ni * 32;
+                    const int xi = (kc * 2 + kgl) * NPX + off + ni * 32;
                     xh[ni] = *reinterpret_cast<const bf16x8 *>(&s_ah[xi]);
                     xl[ni] = *reinterpret_cast<const bf16x8 *>(&s_al[xi]);
                 }
@@ -193,9 +202,9 @@ __global__ __launch_bounds__(256, (WM * MF == 1) ? 4 : (WM * MF == 2 ? 3 : GTTS_
             }
         }
     };
-    for (int chunk = 0; chunk < a.nchunk; chunk += 2) {
+    for (int chunk = 0; chunk < nsteps; chunk += 2) {
         do_chunk(chunk, std::integral_constant<int, 0>{});
-        if (chunk + 1 < a.nchunk) do_chunk(chunk + 1, std::integral_constant<int, 1>{});
+        if (chunk + 1 < nsteps) do_chunk(chunk + 1, std::integral_constant<int, 1>{});
     }
 
     // ---- epilogue: bias, ResBlock residual, running sum over ResBlocks (reference operation order, fp32).
@@ -334,26 +343,26 @@ __global__ __launch_bounds__(256, (WM * MF == 1) ? 4 : (WM * MF == 2 ? 3 : GTTS_
     }
 }
 
-template <int WM, int WN, int MF, int TPS, int AITER>
+template <int WM, int WN, int MF, int TPS, int AITER, int KCH = 1>
 static hipError_t launch_c1_cfg(const C1Args &a, hipStream_t st) {
     constexpr int MT = WM * MF * 32, NT = WN * 64;
     const int M = a.cout * a.S;
     const int ncot = (M + MT - 1) / MT, ntile = (a.Lin + NT - 1) / NT;
-    const size_t smem = (size_t)2 * 2 * a.npx * 16 + (size_t)2 * TPS * 2 * MT * 16;
-    if ((size_t)2 * a.npx > (size_t)AITER * 256) return hipErrorInvalidValue;
+    const size_t smem = (size_t)2 * 2 * KCH * a.npx * 16 + (size_t)KCH * 2 * TPS * 2 * MT * 16;
+    if ((size_t)2 * KCH * a.npx > (size_t)AITER * 256 || a.nchunk % KCH != 0) return hipErrorInvalidValue;
     // the attribute is per device and sticky: raise it once per (instance, device) to the largest image any layer needs
     static std::atomic<unsigned long long> attr_done{0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    constexpr size_t SMEM_MAX = (size_t)2 * 2 * (AITER * 128) * 16 + (size_t)2 * TPS * 2 * MT * 16;
+    constexpr size_t SMEM_MAX = (size_t)2 * 2 * (AITER * 128) * 16 + (size_t)KCH * 2 * TPS * 2 * MT * 16;
     if (smem > SMEM_MAX) return hipErrorInvalidValue;
     if (!((attr_done.load(std::memory_order_relaxed) >> dev) & 1ull)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1d_mfma_kernel<WM, WN, MF, TPS, AITER>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1d_mfma_kernel<WM, WN, MF, TPS, AITER, KCH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_MAX);
         if (e != hipSuccess) return e;
         attr_done.fetch_or(1ull << dev, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, MF, TPS, AITER>), dim3((unsigned)(ncot * ntile * a.B)), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, MF, TPS, AITER, KCH>), dim3((unsigned)(ncot * ntile * a.B)), dim3(256), smem, st, a);
     return hipGetLastError();
 }
 
@@ -372,6 +381,13 @@ static hipError_t launch_c1_t(const C1Args &a, hipStream_t st) {
     const int M = a.cout * a.S;
     const C1Geom g = c1_geom(M, TPS == 3 ? 3 : 4);
     const int aiter = (2 * a.npx + 255) / 256;
+    if constexpr (TPS == 3) {
+        // three-tap layers on the 128-row tile: 32 channels per step when the channel count allows it (see the kernel comment)
+        if (g.MT == 128 && a.nchunk % 2 == 0 && a.cin % 32 == 0) {
+            const int aiter2 = (4 * a.npx + 255) / 256;
+            if (aiter2 <= 3) return launch_c1_cfg<2, 2, 2, 3, 3, 2>(a, st);
+        }
+    }
     if (g.MT == 128) {
         if (aiter <= 2) return launch_c1_cfg<2, 2, 2, TPS, 2>(a, st);
         if (aiter == 3) return launch_c1_cfg<2, 2, 2, TPS, 3>(a, st);
