@@ -366,282 +366,6 @@ static hipError_t launch_c1_cfg(const C1Args &a, hipStream_t st) {
     return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// One ResBlock1 pair in one launch for the narrow stages (C = 32 / 64: one row tile holds every channel):
-//     out = c2(lrelu(c1(lrelu(x)) + b1)) + b2 + x      [running sum over ResBlocks as in the unfused epilogue]
-// (Grad-TTS/hifi-gan/models.py:37-44).  At C <= 64 the two convolutions are HBM-bound -- 4.0 - 4.2 TB/s -- and move 2.5x the
-// minimal traffic between them (T1 written and re-read, x read twice).  Here the intermediate never leaves the CU:
-//   phase A  the unfused main loop on a 256-position tile of T1 (x staged with LeakyReLU + hi/lo split, weights of c1);
-//   hand-off T1 + b1 -> LeakyReLU -> zero outside [0, L) (c2's zero padding) -> hi/lo -> an LDS image in the fragment layout;
-//   phase B  c2's taps straight from that image (no global loads, no staging arithmetic) for the 224 positions whose +-16 halo
-//            is inside the tile; the epilogue adds b2, the residual x (re-read: it is L2-hot) and the ResBlock sum modes.
-// Per output element the MFMA order of each convolution is that of the unfused kernel: results are bit-identical to it.
-struct C1PairArgs {
-    const float *x;          // [B][C][L]: input of c1 AND the residual
-    float *out;              // [B][C][L]
-    const float *accsrc;     // running sum over ResBlocks (accmode 1 / 2) or nullptr
-    const unsigned char *w1, *w2;   // packed like the unfused layers ([chunk][stage][cot = 0][split][tap][kg][MT][8])
-    const float *b1, *b2;
-    int B, C, L, nst;
-    int toff1[C1_MAXTAP], toff2[C1_MAXTAP];
-    int halo1;               // (K - 1) / 2 * dilation of c1
-    float slope;
-    int accmode;
-    float div;
-};
-constexpr int C1P_T1 = 256, C1P_HB = 16, C1P_NQ = C1P_T1 - 2 * C1P_HB;
-
-template <int MF, int TPS, int AITER>
-__global__ __launch_bounds__(256, 2) void conv1d_pair_kernel(const C1PairArgs a) {
-    constexpr int MT = MF * 32, NKG = 2;
-    constexpr int WBLK16 = 2 * TPS * NKG * MT;
-    constexpr int WITER = (WBLK16 + 255) / 256;
-    constexpr int NKT = MT / 8;                                 // 8-channel groups of the T1 image
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int NPX = C1P_T1 + 2 * a.halo1;
-    u32x4 *s_ah = reinterpret_cast<u32x4 *>(smem);             // [NKG][NPX]
-    u32x4 *s_al = s_ah + NKG * NPX;
-    u32x4 *s_w = s_al + NKG * NPX;                             // [split][tap][kg][MT]
-    u32x4 *s_th = s_w + WBLK16;                                // [NKT][C1P_T1] hi
-    u32x4 *s_tl = s_th + NKT * C1P_T1;                         // lo
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, kgl = lane >> 5;
-    const int ntile = (a.L + C1P_NQ - 1) / C1P_NQ;
-    const int wg = xcd_slot(blockIdx.x, gridDim.x);
-    const int tile = wg % ntile, b = wg / ntile;
-    const int q0 = tile * C1P_NQ, p0 = q0 - C1P_HB;            // first output position / first T1 position of the tile
-    const float *xb = a.x + (size_t)b * a.C * a.L;
-    const int nchunk = a.C / 16;
-
-    int it_voff[AITER];
-    const int xbytes = a.C * a.L * 4;
-    auto rsrc = [&](const float *p) {
-        const unsigned long long u = reinterpret_cast<unsigned long long>(p);
-        return __builtin_amdgcn_make_buffer_rsrc(
-            reinterpret_cast<void *>(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(u >> 32)) << 32) |
-                                     (unsigned)__builtin_amdgcn_readfirstlane((unsigned)u)),
-            0, __builtin_amdgcn_readfirstlane(xbytes), 0x00020000);
-    };
-    const __amdgpu_buffer_rsrc_t rsx = rsrc(xb);
-#pragma unroll
-    for (int it = 0; it < AITER; ++it) {
-        const int idx = tid + it * 256;
-        const int p = idx % NPX;
-        const int t = p0 - a.halo1 + p;
-        const bool ok = idx < NKG * NPX && t >= 0 && t < a.L;
-        it_voff[it] = ok ? (min(idx / NPX, NKG - 1) * 8 * a.L + t) * 4 : xbytes;
-    }
-    float araw[AITER][8];
-    auto load_act = [&](int chunk) {
-#pragma unroll
-        for (int it = 0; it < AITER; ++it)
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                araw[it][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, it_voff[it], (chunk * 16 + i) * a.L * 4, 0));
-    };
-    u32x4 wregs[WITER];
-    auto load_w = [&](const unsigned char *w, int chunk, int stage) {
-        const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(w) + ((size_t)chunk * a.nst + stage) * WBLK16;
-#pragma unroll
-        for (int i = 0; i < WITER; ++i) {
-            const int u = tid + i * 256;
-            wregs[i] = wsrc[u < WBLK16 ? u : 0];
-        }
-    };
-    auto put_w = [&]() {
-#pragma unroll
-        for (int i = 0; i < WITER; ++i) {
-            const int u = tid + i * 256;
-            if (u < WBLK16) s_w[u] = wregs[i];
-        }
-    };
-    f32x16 acc[MF][2];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int mi = 0; mi < MF; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    };
-    // MFMAs of one weight stage: B fragments at image position xoff(tap) + ni * 32 of 8-channel group kgbase + kgl
-    auto mfma_stage = [&](const u32x4 *img_h, const u32x4 *img_l, int pitch, int kgbase, int stage, const int *toff, int base, bool second_ok) {
-#pragma unroll
-        for (int j = 0; j < TPS; ++j) {
-            const int off = base + toff[stage * TPS + j] + wn * 64 + l31;
-            bf16x8 wh[MF], wl[MF], xh[2], xl[2];
-#pragma unroll
-            for (int mi = 0; mi < MF; ++mi) {
-                const int wi = (j * NKG + kgl) * MT + mi * 32 + l31;
-                wh[mi] = *reinterpret_cast<const bf16x8 *>(&s_w[wi]);
-                wl[mi] = *reinterpret_cast<const bf16x8 *>(&s_w[wi + TPS * NKG * MT]);
-            }
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                if (ni == 1 && !second_ok) continue;
-                const int xi = (kgbase + kgl) * pitch + off + ni * 32;
-                xh[ni] = *reinterpret_cast<const bf16x8 *>(&img_h[xi]);
-                xl[ni] = *reinterpret_cast<const bf16x8 *>(&img_l[xi]);
-            }
-#pragma unroll
-            for (int mi = 0; mi < MF; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    if (ni == 1 && !second_ok) continue;
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[mi], xh[ni], acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[mi], xl[ni], acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[mi], xh[ni], acc[mi][ni], 0, 0, 0);
-                }
-        }
-    };
-
-    // ---------------------------------------------------------------- phase A: T1 = c1(lrelu(x)) on the tile's 256 positions
-    zero_acc();
-    load_w(a.w1, 0, 0);
-    load_act(0);
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
-        lds_barrier();
-#pragma unroll
-        for (int it = 0; it < AITER; ++it) {
-            const int idx = tid + it * 256;
-            bf16x8 vh, vl;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float v = araw[it][i];
-                v = v > 0.f ? v : v * a.slope;                    // F.leaky_relu(x, slope)
-                __bf16 h, l;
-                split_bf16(v, h, l);
-                vh[i] = h;
-                vl[i] = l;
-            }
-            if (idx < NKG * NPX) {
-                s_ah[idx] = *reinterpret_cast<u32x4 *>(&vh);
-                s_al[idx] = *reinterpret_cast<u32x4 *>(&vl);
-            }
-        }
-        if (chunk + 1 < nchunk) load_act(chunk + 1);
-        for (int stage = 0; stage < a.nst; ++stage) {
-            if (stage > 0) lds_barrier();
-            put_w();
-            lds_barrier();
-            if (stage + 1 < a.nst) load_w(a.w1, chunk, stage + 1);
-            else if (chunk + 1 < nchunk) load_w(a.w1, chunk + 1, 0);
-            else load_w(a.w2, 0, 0);                              // first stage of c2: in flight across the hand-off
-            mfma_stage(s_ah, s_al, NPX, 0, stage, a.toff1, a.halo1, true);
-        }
-    }
-    // ---------------------------------------------------------------- hand-off: T1 -> LDS image [8-channel group][position]
-    {
-        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int pos = wn * 64 + ni * 32 + l31;
-            const int gp = p0 + pos;
-            const bool inside = gp >= 0 && gp < a.L;               // outside the sequence c2 sees its zero padding, not c1's values
-#pragma unroll
-            for (int mi = 0; mi < MF; ++mi)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    bf16x4_t h4, l4;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int c = mi * 32 + 8 * g + 4 * kgl + i;
-                        float v = acc[mi][ni][4 * g + i] + a.b1[c];
-                        v = v > 0.f ? v : v * a.slope;
-                        v = inside ? v : 0.f;
-                        __bf16 h, l;
-                        split_bf16(v, h, l);
-                        h4[i] = h;
-                        l4[i] = l;
-                    }
-                    const int slot = (mi * 4 + g) * C1P_T1 + pos;  // 16-byte slot of (8-channel group, position); this lane's half: kgl
-                    *(reinterpret_cast<bf16x4_t *>(&s_th[slot]) + kgl) = h4;
-                    *(reinterpret_cast<bf16x4_t *>(&s_tl[slot]) + kgl) = l4;
-                }
-        }
-    }
-    // ---------------------------------------------------------------- phase B: c2 on the 224 inner positions
-    zero_acc();
-    const bool second_ok = wn * 64 + 32 < C1P_NQ;                  // the last wave's second 32-position block is outside the tile
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
-        for (int stage = 0; stage < a.nst; ++stage) {
-            lds_barrier();                                        // previous MFMAs are done with s_w (first pass: the T1 image is written)
-            put_w();
-            lds_barrier();
-            if (stage + 1 < a.nst) load_w(a.w2, chunk, stage + 1);
-            else if (chunk + 1 < nchunk) load_w(a.w2, chunk + 1, 0);
-            mfma_stage(s_th, s_tl, C1P_T1, 2 * chunk, stage, a.toff2, C1P_HB, second_ok);
-        }
-    }
-    // ---------------------------------------------------------------- epilogue: + b2 + x (+ running sum), buffer descriptors
-    const size_t ob = (size_t)b * a.C * a.L;
-    const __amdgpu_buffer_rsrc_t rs_out = rsrc(a.out + ob);
-    const __amdgpu_buffer_rsrc_t rs_acc = rsrc(a.accsrc ? a.accsrc + ob : a.out + ob);
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int o = wn * 64 + ni * 32 + l31, q = q0 + o;
-        const int voff = (o < C1P_NQ && q < a.L) ? (4 * kgl * a.L + q) * 4 : xbytes;
-#pragma unroll
-        for (int mi = 0; mi < MF; ++mi) {
-            float rv[16], av[16];
-#pragma unroll
-            for (int rg = 0; rg < 16; ++rg)
-                rv[rg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, voff, (mi * 32 + (rg & 3) + 8 * (rg >> 2)) * a.L * 4, 0));
-            if (a.accmode != 0) {
-#pragma unroll
-                for (int rg = 0; rg < 16; ++rg)
-                    av[rg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_acc, voff, (mi * 32 + (rg & 3) + 8 * (rg >> 2)) * a.L * 4, 0));
-            }
-#pragma unroll
-            for (int rg = 0; rg < 16; ++rg) {
-                const int c = mi * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kgl;
-                float v = acc[mi][ni][rg] + a.b2[c];
-                v = v + rv[rg];
-                if (a.accmode == 1) v = av[rg] + v;
-                else if (a.accmode == 2) v = __fdiv_rn(av[rg] + v, a.div);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs_out, voff, (mi * 32 + (rg & 3) + 8 * (rg >> 2)) * a.L * 4, 0);
-            }
-        }
-    }
-}
-
-static inline bool conv1d_pair_eligible(int C, int K, int dil) {
-    return (C == 32 || C == 64) && K % 2 == 1 && K >= 3 && K <= C1_MAXTAP - 1 && (K - 1) / 2 <= C1P_HB && (K - 1) / 2 * dil <= 64;
-}
-template <int MF, int TPS>
-static hipError_t launch_c1_pair_cfg(const C1PairArgs &a, hipStream_t st) {
-    constexpr int MT = MF * 32;
-    const int npx = C1P_T1 + 2 * a.halo1;
-    if (2 * npx > 3 * 256) return hipErrorInvalidValue;
-    const size_t smem = ((size_t)2 * 2 * npx + (size_t)2 * TPS * 2 * MT + (size_t)2 * (MT / 8) * C1P_T1) * 16;
-    constexpr size_t SMEM_MAX = ((size_t)2 * 2 * 384 + (size_t)2 * TPS * 2 * MT + (size_t)2 * (MT / 8) * C1P_T1) * 16;
-    static std::atomic<unsigned long long> attr_done{0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!((attr_done.load(std::memory_order_relaxed) >> dev) & 1ull)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1d_pair_kernel<MF, TPS, 3>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_MAX);
-        if (e != hipSuccess) return e;
-        attr_done.fetch_or(1ull << dev, std::memory_order_relaxed);
-    }
-    const int ntile = (a.L + C1P_NQ - 1) / C1P_NQ;
-    hipLaunchKernelGGL((conv1d_pair_kernel<MF, TPS, 3>), dim3((unsigned)(ntile * a.B)), dim3(256), smem, st, a);
-    return hipGetLastError();
-}
-// K taps with dilation dil1 then K taps with dilation 1; both packed by launch_pack_conv1d for (C, C, K)
-static inline hipError_t launch_conv1d_pair(C1PairArgs a, int K, int dil1, hipStream_t st) {
-    if (!conv1d_pair_eligible(a.C, K, dil1)) return hipErrorInvalidValue;
-    if ((size_t)a.C * a.L * 4 >= ((size_t)1 << 31)) return hipErrorInvalidValue;
-    const int tps = K <= 3 ? 3 : 4;
-    a.nst = (K + tps - 1) / tps;
-    for (int t = 0; t < C1_MAXTAP; ++t) { a.toff1[t] = 0; a.toff2[t] = 0; }
-    for (int t = 0; t < K; ++t) { a.toff1[t] = (t - (K - 1) / 2) * dil1; a.toff2[t] = t - (K - 1) / 2; }
-    a.halo1 = (K - 1) / 2 * dil1;
-    if (a.C == 32) return tps == 3 ? launch_c1_pair_cfg<1, 3>(a, st) : launch_c1_pair_cfg<1, 4>(a, st);
-    return tps == 3 ? launch_c1_pair_cfg<2, 3>(a, st) : launch_c1_pair_cfg<2, 4>(a, st);
-}
-
 // tiling of a layer by its row count M = cout * S (must agree with the packer below)
 struct C1Geom { int MT, NT, tps; };
 static C1Geom c1_geom(int M, int ntap_real) {

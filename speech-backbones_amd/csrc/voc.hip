@@ -275,26 +275,6 @@ static int voc_run_layer(const gtts_voc *v, const unsigned char *blob, int li, c
     return GTTS_OK;
 }
 
-// One ResBlock1 pair (convs1[d], convs2[d]) as ONE launch for the narrow stages (conv1d_pair_kernel): out = c2(lrelu(c1(lrelu(x)))) + x
-static int voc_run_pair(const gtts_voc *v, const unsigned char *blob, int l1, int l2, const float *x, float *out, const float *accsrc,
-                        int accmode, float slope, int B, int L, hipStream_t st) {
-    const VocLayer &A = v->layers[l1], &Bq = v->layers[l2];
-    C1PairArgs a;
-    a.x = x; a.out = out; a.accsrc = accsrc;
-    a.w1 = blob + A.w_off; a.b1 = (const float *)(blob + A.b_off);
-    a.w2 = blob + Bq.w_off; a.b2 = (const float *)(blob + Bq.b_off);
-    a.B = B; a.C = A.cout; a.L = L; a.nst = A.nst;
-    a.slope = slope; a.accmode = accmode; a.div = (float)v->cfg.n_kernels;
-    const hipError_t e = launch_conv1d_pair(a, A.K, A.dil, st);
-    if (e != hipSuccess) return vfail(GTTS_E_HIP, "conv1d pair %s: %s", A.name.c_str(), hipGetErrorString(e));
-    return GTTS_OK;
-}
-static bool voc_pair_ok(const gtts_voc *v, int l1, int l2) {
-    const VocLayer &A = v->layers[l1], &Bq = v->layers[l2];
-    return A.mode == 0 && Bq.mode == 0 && A.cin == A.cout && Bq.cin == A.cout && Bq.cout == A.cout && A.K == Bq.K && Bq.dil == 1 &&
-           A.S == 1 && Bq.S == 1 && A.MT == A.cout && Bq.MT == A.cout && conv1d_pair_eligible(A.cout, A.K, A.dil);
-}
-
 // Generator.forward (models.py:103-120): mel [B, n_mels, T] -> wav [B, 1, T * hop]
 extern "C" int gtts_voc_forward(const gtts_voc *v, const void *packed, const float *mel, float *wav, void *workspace,
                                 size_t workspace_bytes, int B, int T, gtts_stream_t stream) {
@@ -328,25 +308,14 @@ extern "C" int gtts_voc_forward(const gtts_voc *v, const void *packed, const flo
             const int accmode = j == 0 ? 0 : (j + 1 < nk ? 1 : 2);
             if (v->cfg.resblock_type == 1) {
                 // ResBlock1 (:37-44): three times  xt = c2(lrelu(c1(lrelu(x))));  x = xt + x
-                const float *xin = X;
                 for (int d = 0; d < 3; ++d) {
-                    const bool last = d == 2;
-                    if (voc_pair_ok(v, ids[d], ids[3 + d])) {
-                        // narrow stages: the pair in one launch, the intermediate in LDS.  The output must not alias the input (other
-                        // workgroups still read its halo): R and the otherwise unused T1 buffer alternate
-                        float *dst = last ? XS : (xin == R ? T1 : R);
-                        rc = voc_run_pair(v, blob, ids[d], ids[3 + d], xin, dst, last && accmode ? XS : nullptr, last ? accmode : 0, LR, B,
-                                          (int)len, st);
-                        if (rc) return rc;
-                        xin = dst;
-                        continue;
-                    }
+                    const float *xin = d == 0 ? X : R;
                     rc = voc_run_layer(v, blob, ids[d], xin, T1, nullptr, nullptr, 0, LR, B, (int)len, st);
                     if (rc) return rc;
+                    const bool last = d == 2;
                     rc = voc_run_layer(v, blob, ids[3 + d], T1, last ? XS : R, xin, last && accmode ? XS : nullptr,
                                        last ? accmode : 0, LR, B, (int)len, st);
                     if (rc) return rc;
-                    xin = R;
                 }
             } else {
                 // ResBlock2 (:66-71): twice  x = c(lrelu(x)) + x
