@@ -15,7 +15,9 @@ from oracle import gradtts_oracle as O  # noqa: E402  (weights only; this is a d
 B, T = 16, 1024
 dev = torch.device("cuda:0")
 sd = O.make_estimator_state(seed=0)
-plan = S.Plan(n_spks=1)
+prec = {"bf16x3": S.PREC_BF16X3, "bf16": S.PREC_BF16, "bf16_store": S.PREC_BF16_STORE}[os.environ.get("TRACE_PREC", "bf16x3")]
+plan = S.Plan(n_spks=1, precision=prec)
+print("precision", os.environ.get("TRACE_PREC", "bf16x3"))
 packed = plan.pack(sd, dev)
 g = torch.Generator().manual_seed(0)
 x = torch.randn(B, 80, T, generator=g).to(dev)
