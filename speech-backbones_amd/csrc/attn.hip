@@ -17,6 +17,11 @@
 #include "common.h"
 #include "kernels.h"
 
+// heads per workgroup of the per-head context kernel (C >= 128): see attn_ctx_kernel
+#ifndef GTTS_ATTN_HPW
+#define GTTS_ATTN_HPW 2
+#endif
+
 namespace gtts {
 
 struct AttnCtxArgs {
@@ -43,26 +48,44 @@ __device__ __forceinline__ void pack8_split(const float (&v)[8], u32x4 &hi, u32x
 // (Measured and not kept, round 3: head PAIRS per workgroup -- the x tile loaded, split and staged once for two heads, each
 // head with its own projection accumulators / softmax state / context, records bit-identical.  128 + 32 accumulator registers
 // beside the 32-register x prefetch do not fit 256 VGPRs: 54 spilled registers, 81.6 vs 62.0 us per launch.)
-template <int NSPLIT, int FULLC, typename AT = float>
-__global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
+// HPW = heads per workgroup (256 threads per head).  HPW = 2: the x tile is loaded, split into bf16 hi/lo and staged ONCE for
+// two heads by 512 threads -- half the staging work per wave (the kernel issues ten VALU instructions per MFMA, more than
+// half of them in the staging); every wave does exactly the arithmetic of the one-head form on the same pixels in the same
+// order and the four waves of a head are merged as before, so the records are bit-identical.  One 8-wave workgroup per CU =
+// the two waves per SIMD of the one-head form.  Measured (B = 16, one stream, alternating repeats on one box): C = 128 at
+// 40 x 512: 117.3 -> 103.8 us; C = 256 at 20 x 256: 58.5 -> 57.8 us (one tile per workgroup: prologue, merge and the launch's
+// tail bound it, not the staging); sampler outputs bit-identical in all three precisions.
+template <int NSPLIT, int FULLC, typename AT = float, int HPW = 1>
+__global__ __launch_bounds__(256 * HPW, HPW == 1 ? 2 : 1) void attn_ctx_kernel(const AttnCtxArgs a) {
     constexpr int AB = (int)sizeof(AT);
     constexpr int KCH = ATTN_KCH, NKG = 2 * KCH;
-    __shared__ __attribute__((aligned(16))) u32x4 s_ah[NKG * 256];
-    __shared__ __attribute__((aligned(16))) u32x4 s_al[NKG * 256];
-    __shared__ __attribute__((aligned(16))) u32x4 s_w[2 * NKG * 64];     // [split][kg][64 rows: k_h(32) | v_h(32)]
+    constexpr int NKGT = NKG / HPW;                     // channel groups a thread loads and stages per stage
+    constexpr int WHEAD = 2 * NKG * 64;                 // 16-byte units of one head's weight stage
+    static_assert(HPW == 1 || HPW == 2, "one or two heads per workgroup");
+    // one buffer: [x hi NKG*256][x lo NKG*256][weights HPW * WHEAD]; the final merge re-uses it as [4 HPW waves][ATTN_REC] floats
+    constexpr int SM16 = 2 * NKG * 256 + HPW * WHEAD;
+    static_assert((size_t)SM16 * 16 >= (size_t)4 * HPW * ATTN_REC * 4, "merge records must fit the staging buffer");
+    __shared__ __attribute__((aligned(16))) u32x4 s_all[SM16];
+    u32x4 *s_ah = s_all, *s_al = s_all + NKG * 256;
+    u32x4 *s_wall = s_all + 2 * NKG * 256;                // [head in workgroup][split][kg][64 rows: k_h(32) | v_h(32)]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // hw: this thread's head inside the workgroup (staging AND compute), as an SGPR: it selects channel offsets of buffer loads
+    const int t255 = tid & 255, hw = __builtin_amdgcn_readfirstlane(tid >> 8);
+    const int wave = (tid >> 6) & 3;                      // pixel quarter of the 256-pixel tile
     const int l31 = lane & 31, kgl = lane >> 5;
     // XCD-banded order with the four heads of a pixel slice adjacent: they read the same x tiles (L2 hits)
-    const int nsl = gridDim.x / (4 * a.B);
+    constexpr int HG = 4 / HPW;                           // workgroups per pixel slice
+    const int nsl = gridDim.x / (HG * a.B);
     const int wg = xcd_slot(blockIdx.x, gridDim.x);
-    const int head = wg & 3, slice = (wg >> 2) % nsl, b = (wg >> 2) / nsl;
+    const int head = (wg % HG) * HPW + hw, slice = (wg / HG) % nsl, b = (wg / HG) / nsl;
+    u32x4 *s_w = s_wall + hw * WHEAD;
     const int tile0 = slice * a.tps;
     const int tile1 = min(tile0 + a.tps, a.tiles);
     const AT *xb = reinterpret_cast<const AT *>(a.x) + (size_t)b * a.C * a.HW;
     const u32x4 *wblk = reinterpret_cast<const u32x4 *>(a.wkv) + (size_t)head * a.nstage * (2 * NKG * 64);
 
-    float raw[NKG][8];
+    float raw[NKGT][8];
     u32x4 wregs[KCH];
     // Buffer loads: the lane's pixel is the per-lane byte offset, the channel offset is an SGPR -> no VALU address
     // arithmetic.  Pixels >= HW get a per-lane offset equal to the descriptor size: the bounds check (which covers the
@@ -75,11 +98,11 @@ __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<void *>(((unsigned long long)xhi << 32) | xlo), 0, __builtin_amdgcn_readfirstlane(xbytes), 0x00020000);
     auto load = [&](int tile, int stage) {
-        const int n = tile * 256 + tid;
+        const int n = tile * 256 + t255;
         const int voff = n < a.HW ? n * AB : xbytes;
 #pragma unroll
-        for (int kg = 0; kg < NKG; ++kg) {
-            const int cb = stage * 16 * KCH + kg * 8;
+        for (int kg = 0; kg < NKGT; ++kg) {
+            const int cb = stage * 16 * KCH + (hw * NKGT + kg) * 8;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int c = FULLC ? cb + i : min(cb + i, a.C - 1);
@@ -91,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
         }
         const u32x4 *g = wblk + (size_t)stage * (2 * NKG * 64);
 #pragma unroll
-        for (int j = 0; j < KCH; ++j) wregs[j] = g[tid + j * 256];
+        for (int j = 0; j < KCH; ++j) wregs[j] = g[t255 + j * 256];
     };
 
     const float NEG_INF = -__builtin_inff();
@@ -114,14 +137,14 @@ __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
         for (int stage = 0; stage < a.nstage; ++stage) {
             lds_barrier();
 #pragma unroll
-            for (int kg = 0; kg < NKG; ++kg) {
+            for (int kg = 0; kg < NKGT; ++kg) {
                 u32x4 hi, lo;
                 pack8_split(raw[kg], hi, lo);
-                s_ah[kg * 256 + tid] = hi;
-                s_al[kg * 256 + tid] = lo;
+                s_ah[(hw * NKGT + kg) * 256 + t255] = hi;
+                s_al[(hw * NKGT + kg) * 256 + t255] = lo;
             }
 #pragma unroll
-            for (int j = 0; j < KCH; ++j) s_w[tid + j * 256] = wregs[j];
+            for (int j = 0; j < KCH; ++j) s_w[t255 + j * 256] = wregs[j];
             lds_barrier();
             if (stage + 1 < a.nstage) load(tile, stage + 1);
             else if (tile + 1 < tile1) load(tile + 1, 0);
@@ -238,7 +261,8 @@ __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
 
     // ---- merge the four waves' partials (log-sum-exp, fixed order) -> one record per workgroup:
     // m[32], Z[32], ctx[32][32] (relative to m)
-    __shared__ float s_mrg[4][ATTN_REC];
+    __syncthreads();                                   // every wave is done with the staging buffer: it becomes the merge buffer
+    float (*s_mrg)[ATTN_REC] = reinterpret_cast<float (*)[ATTN_REC]>(s_all) + hw * 4;      // this head's four records
     {
         float *mine = s_mrg[wave];
         if (kgl == 0) {
@@ -255,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void attn_ctx_kernel(const AttnCtxArgs a) {
     float *rec = a.partials + ((((size_t)b * 4 + head) * a.nrec) + (size_t)slice) * ATTN_REC;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int idx = tid + 256 * k, d = idx >> 5;
+        const int idx = t255 + 256 * k, d = idx >> 5;
         float M = NEG_INF;
 #pragma unroll
         for (int w = 0; w < 4; ++w) M = fmaxf(M, s_mrg[w][d]);
@@ -495,19 +519,20 @@ hipError_t launch_attn_ctx(const void *x, const unsigned char *wkv, float *parti
         else hipLaunchKernelGGL((attn_ctx64_kernel<1, float>), grid64, dim3(256), 0, st, a);
         return hipGetLastError();
     }
-    const dim3 grid(g.nslices * 4 * B);
+    constexpr int HPW = GTTS_ATTN_HPW;
+    const dim3 grid(g.nslices * (4 / HPW) * B), block(256 * HPW);
     if (act_bf16) {
         if (nsplit > 1) return hipErrorInvalidValue;
-        if (C % 32 == 0) hipLaunchKernelGGL((attn_ctx_kernel<1, 1, __bf16>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((attn_ctx_kernel<1, 0, __bf16>), grid, dim3(256), 0, st, a);
+        if (C % 32 == 0) hipLaunchKernelGGL((attn_ctx_kernel<1, 1, __bf16, HPW>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((attn_ctx_kernel<1, 0, __bf16, HPW>), grid, block, 0, st, a);
         return hipGetLastError();
     }
     if (C % 32 == 0) {
-        if (nsplit > 1) hipLaunchKernelGGL((attn_ctx_kernel<2, 1>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((attn_ctx_kernel<1, 1>), grid, dim3(256), 0, st, a);
+        if (nsplit > 1) hipLaunchKernelGGL((attn_ctx_kernel<2, 1, float, HPW>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((attn_ctx_kernel<1, 1, float, HPW>), grid, block, 0, st, a);
     } else {
-        if (nsplit > 1) hipLaunchKernelGGL((attn_ctx_kernel<2, 0>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((attn_ctx_kernel<1, 0>), grid, dim3(256), 0, st, a);
+        if (nsplit > 1) hipLaunchKernelGGL((attn_ctx_kernel<2, 0, float, HPW>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((attn_ctx_kernel<1, 0, float, HPW>), grid, block, 0, st, a);
     }
     return hipGetLastError();
 }

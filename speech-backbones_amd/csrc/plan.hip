@@ -1457,7 +1457,7 @@ extern "C" int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, con
                 if (attn_head_per_wave(o.C))
                     snprintf(nb, sizeof nb, "gtts::attn_ctx64_kernel<%d, %s>", plan->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1, abf ? "__bf16" : "float");
                 else
-                    snprintf(nb, sizeof nb, "gtts::attn_ctx_kernel<%d, %d, %s>", plan->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1, o.C % 32 == 0 ? 1 : 0,
+                    snprintf(nb, sizeof nb, "gtts::attn_ctx_kernel<%d, %d, %s, 2>", plan->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1, o.C % 32 == 0 ? 1 : 0,
                              abf ? "__bf16" : "float");
                 s_kernel = nb;
                 fl = 2.0 * B * Hi * Wi * (256.0 * o.C + 128.0 * 32);
