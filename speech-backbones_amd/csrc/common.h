@@ -56,6 +56,9 @@ __device__ __forceinline__ int xcd_slot(int id, int n) {
 }
 
 __device__ __forceinline__ float mish_f(float x) {
+    // no implicit mul+add fusion in here: `n + 2` may or may not be contracted with the multiply that produced n (n has a
+    // second use), and the choice can differ between template instances that must agree bit for bit (conv_mfma.hip)
+#pragma clang fp contract(off)
     float e = __expf(fminf(x, 40.0f));
     float n = e * (e + 2.0f);
     return x * (n * __builtin_amdgcn_rcpf(n + 2.0f));

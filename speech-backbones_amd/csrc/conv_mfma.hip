@@ -129,6 +129,13 @@ extern "C" int gtts_debug_trace(unsigned long long *dst, int n) {
 #define TR_MARK(ph) do { } while (0)
 #endif
 
+// Several instances of this kernel must produce the same bits for the same layer (regular and half-height tiles are picked by
+// launch size, and results must not depend on how utterances are batched).  hipcc's default -ffp-contract=fast fuses a multiply
+// with a following add where it sees fit, and it can see fit differently in different instances (measured on an experimental
+// third instance of the 3x3 kernel: five more v_pk_fma_f32 in the statistics epilogue, GroupNorm shifts off by one ulp): every
+// fused multiply-add in this file is therefore written as fmaf / fma explicitly, and implicit contraction is off.
+#pragma clang fp contract(off)
+
 namespace gtts {
 
 template <int MODE, int WM, int WN, int MF, int KCH, int NF = 2>
@@ -444,13 +451,13 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
                 if (PRO == PRO_MASK) {
                     v *= m;
                 } else if (PRO == PRO_GN) {
-                    const float y = v * sc[i] + sh[i];
-                    v = (mish_f(y) * m + tb[i]) * m;
+                    const float y = fmaf(v, sc[i], sh[i]);
+                    v = fmaf(mish_f(y), m, tb[i]) * m;
                 } else if (PRO == PRO_IGLU) {
-                    const float ga = v * sc[i] + sh[i];
-                    const float gb = brawst[it][i] * scb[i] + shb[i];
+                    const float ga = fmaf(v, sc[i], sh[i]);
+                    const float gb = fmaf(brawst[it][i], scb[i], shb[i]);
                     const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-gb));     // sigmoid
-                    v = (ga * sg + tb[i]) * m;
+                    v = fmaf(ga, sg, tb[i]) * m;
                     if (!FULLC) v = (inb && i < nval) ? v : 0.f;
                 }
                 if constexpr (NSPLIT > 1) {
@@ -709,8 +716,8 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
                     const int col = m0 + mi * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kg_l;   // channel inside the tile
                     float v = acc[mi][ni][rg] + s_epi[col];
                     if (EPI == EPI_TAIL) {
-                        const float y = ex[rg] * s_epi[MT + col] + s_epi[2 * MT + col];
-                        v += mish_f(y) * m_out;
+                        const float y = fmaf(ex[rg], s_epi[MT + col], s_epi[2 * MT + col]);
+                        v = fmaf(mish_f(y), m_out, v);
                     } else if (EPI == EPI_ATTN) {
                         v += ex[rg];
                     } else if (EPI == EPI_PLAIN) {
@@ -721,7 +728,7 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
                     if (EPI == EPI_STATS) {
                         // octet rg>>2 of this 32-channel fragment (static index); octets -> groups below
                         st1[mi][rg >> 2] += v;
-                        st2[mi][rg >> 2] += v * v;
+                        st2[mi][rg >> 2] = fmaf(v, v, st2[mi][rg >> 2]);
                     }
                 }
             }
@@ -866,14 +873,14 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
                     s2 += __shfl_xor(s2, o, 64);
                 }
                 const double mean = s1 / (double)a.gn_count;
-                double var = s2 / (double)a.gn_count - mean * mean;
+                double var = fma(-mean, mean, s2 / (double)a.gn_count);
                 if (var < 0.0) var = 0.0;
                 const double rstd = 1.0 / sqrt(var + 1e-5);
                 if (g < a.groups) {
                     for (int c = g * gs + sub; c < (g + 1) * gs; c += 8) {
                         const double sc = (double)a.gn_gamma[c] * rstd;
                         a.gn_sc[(size_t)b * a.cout + c] = (float)sc;
-                        a.gn_sh[(size_t)b * a.cout + c] = (float)((double)a.gn_beta[c] - mean * sc);
+                        a.gn_sh[(size_t)b * a.cout + c] = (float)fma(-mean, sc, (double)a.gn_beta[c]);
                     }
                 }
                 if (lane == 0) __hip_atomic_store(a.ticket + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
