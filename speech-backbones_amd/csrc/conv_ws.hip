@@ -61,6 +61,10 @@ extern "C" int gtts_debug_trace_ws(unsigned long long *dst, int n) {
 #define WT_ADD(slot, t1, t0) do { } while (0)
 #endif
 
+// the eight-wave and three-wave forms of this kernel must agree bit for bit (results do not depend on the batch): every fused
+// multiply-add is explicit and implicit contraction is off (see conv_mfma.hip)
+#pragma clang fp contract(off)
+
 namespace gtts {
 
 template <int WM, int WN, int MF, int NF>
@@ -153,19 +157,6 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
         const int wtotal = nchunk * 3 * ncotp * WBLK16 * 16;
         const __amdgpu_buffer_rsrc_t rsw = uniform_rsrc(a.w, wtotal);
         const int w_lane = (kg_l * MTP + m0 + l31) * 16;            // lane's row inside a (split, tap, kg) segment of the packing tile
-        // A fragments of (chunk, stage, tap) of cout tile cot: hi [mi], lo [MF + mi]
-        auto wload = [&](bf16x8 (&w)[MF * NSPLIT], int chunk, int stage, int tap, int cot) {
-            const int blk = (chunk * 3 + stage) * ncotp + cot / cpp;
-            const int w_voff = w_lane + (cot % cpp) * MT * 16;
-#pragma unroll
-            for (int sp = 0; sp < NSPLIT; ++sp)
-#pragma unroll
-                for (int mi = 0; mi < MF; ++mi) {
-                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
-                        rsw, w_voff + mi * 32 * 16, blk * (WBLK16 * 16) + ((sp * 3 + tap) * NKG * MTP) * 16, 0);
-                    w[sp * MF + mi] = __builtin_bit_cast(bf16x8, v);
-                }
-        };
         f32x16 acc[MF][NF];
         // Issue order of a tap (bf16x3): pass 1 wl.xh, pass 2 wh.xh, pass 3 wh.xl, each pass over all MF x NF accumulators
         // (two MFMAs on one accumulator are MF*NF issue slots apart).  Everything a pass multiplies was requested at least
@@ -337,7 +328,7 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) {
                                     st1[mi][q] += r[i];
-                                    st2[mi][q] += r[i] * r[i];
+                                    st2[mi][q] = fmaf(r[i], r[i], st2[mi][q]);
                                 }
                                 const int voff = (oy * a.Wout + ox + 4 * kg_l * HW) * AB;
 #pragma unroll
@@ -500,8 +491,8 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
                             if constexpr (PRO == PRO_MASK) {
                                 v *= m;
                             } else {
-                                const float y = v * sc[i] + sh[i];
-                                v = (mish_f(y) * m + tb[i]) * m;
+                                const float y = fmaf(v, sc[i], sh[i]);
+                                v = fmaf(mish_f(y), m, tb[i]) * m;
                             }
                             if constexpr (NSPLIT > 1) {
                                 __bf16 h, l;
@@ -606,14 +597,14 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
                 s2 += __shfl_xor(s2, o, 64);
             }
             const double mean = s1 / (double)a.gn_count;
-            double var = s2 / (double)a.gn_count - mean * mean;
+            double var = fma(-mean, mean, s2 / (double)a.gn_count);
             if (var < 0.0) var = 0.0;
             const double rstd = 1.0 / sqrt(var + 1e-5);
             if (g < a.groups) {
                 for (int c = g * gs + sub; c < (g + 1) * gs; c += 8) {
                     const double sc = (double)a.gn_gamma[c] * rstd;
                     a.gn_sc[(size_t)b * a.cout + c] = (float)sc;
-                    a.gn_sh[(size_t)b * a.cout + c] = (float)((double)a.gn_beta[c] - mean * sc);
+                    a.gn_sh[(size_t)b * a.cout + c] = (float)fma(-mean, sc, (double)a.gn_beta[c]);
                 }
             }
             if (lane == 0) __hip_atomic_store(a.ticket + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
