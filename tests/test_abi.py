@@ -183,3 +183,22 @@ def test_oracle_is_test_infrastructure_only():
         for ch in ast.iter_child_nodes(node):
             walk(ch, fn_stack)
     walk(tree, [])
+
+
+def test_batch_invariant_kernels_do_not_rely_on_implicit_fp_contraction():
+    """Results must not depend on how utterances are batched, and the batch size picks between template instances of the 3x3
+    kernels (regular / half-height tiles, eight- / three-wave persistent form).  Those instances agree bit for bit only if the
+    compiler fuses the same multiply-add pairs in each; with -ffp-contract=fast it did not always.  The
+    two kernel files therefore switch implicit contraction off and spell every fused multiply-add out; this test keeps it so."""
+    csrc = os.path.join(ROOT, "speech-backbones_amd", "csrc")
+    for name in ("conv_mfma.hip", "conv_ws.hip"):
+        src = open(os.path.join(csrc, name)).read()
+        head = src[:src.index("namespace gtts {")]
+        assert "#pragma clang fp contract(off)" in head, name
+        code = re.sub(r"//[^\n]*", "", src)
+        # the statistics and prologue expressions that used to be written as a * b + c
+        assert not re.search(r"\+=\s*\w+(\[\w+\])?\s*\*\s*\w+(\[\w+\])?\s*;", code), name
+        assert "fmaf(" in code, name
+    mish = open(os.path.join(csrc, "common.h")).read()
+    body = mish[mish.index("float mish_f(float x)"):]
+    assert "#pragma clang fp contract(off)" in body[:body.index("}")]
