@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 S = importlib.import_module("speech-backbones_amd")
 from oracle import gradtts_oracle as O  # noqa: E402  (weights only; this is a diagnostic, not the product path)
 
-B, T = 16, 1024
+B, T = int(os.environ.get("TRACE_B", "16")), 1024
 dev = torch.device("cuda:0")
 sd = O.make_estimator_state(seed=0)
 prec = {"bf16x3": S.PREC_BF16X3, "bf16": S.PREC_BF16, "bf16_store": S.PREC_BF16_STORE}[os.environ.get("TRACE_PREC", "bf16x3")]
