@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GTTS_ABI_VERSION 4
+#define GTTS_ABI_VERSION 5
 
 enum {
     GTTS_OK = 0,
@@ -50,9 +50,15 @@ enum {
 enum {
     GTTS_PREC_BF16X3 = 0,    /* split-bf16 (hi/lo, 3 MFMAs, fp32 accumulate): fp32-grade accuracy (default) */
     GTTS_PREC_BF16 = 1,      /* single bf16 MFMA, fp32 accumulate, fp32 activation storage                   */
-    GTTS_PREC_BF16_STORE = 2 /* BASELINE.json config 3 as written: single bf16 MFMA, fp32 accumulate, and every
+    GTTS_PREC_BF16_STORE = 2,/* BASELINE.json config 3 as written: single bf16 MFMA, fp32 accumulate, and every
                                 activation tensor of the U-Net stored as bf16 (weights are bf16 already); GroupNorm
                                 statistics come from the fp32 accumulators before rounding.  Grad-TTS plans only. */
+    GTTS_PREC_F16F8 = 3      /* ABI 5.  fp32-grade like BF16X3 (~2^-17 per product), two MFMA pass-equivalents instead of three
+                                on the 3x3 Block convolutions: x = fp16 hi + residual; hi*hi on the fp16 MFMA, both cross terms
+                                (w * x_lo + w_lo * x, operands rounded to fp8 e4m3) in ONE fp8 MFMA per 32 channels.  Every other
+                                contraction of the plan (1x1, resampling, attention, the 2-channel first layer) stays BF16X3.
+                                Activations beyond +-1024 keep fp16-grade cross terms (the fp8 operand saturates), beyond
+                                65504 they overflow the fp16 half; conv weights must satisfy |w| < 63.  conv_ws is ignored. */
 };
 
 typedef void *gtts_stream_t; /* hipStream_t */

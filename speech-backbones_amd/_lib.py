@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("GTTS_LIB", os.path.join(_HERE, "libgradtts_gfx950.so"
 PREC_BF16X3 = 0
 PREC_BF16 = 1
 PREC_BF16_STORE = 2
+PREC_F16F8 = 3          # fp16 hi*hi + both cross terms in one fp8 MFMA on the 3x3 Block convolutions (ABI 5); fp32-grade like bf16x3
 
 _lib = None
 _lock = threading.Lock()
@@ -196,7 +197,7 @@ def lib():
         L.gtts_ubench_mfma_out_floats.restype = sz
         L.gtts_ubench_mfma.argtypes = [vp, sz, vp, i, i, ctypes.POINTER(ctypes.c_double), vp]
         L.gtts_ubench_hbm.argtypes = [vp, vp, vp, sz, i, i, ctypes.POINTER(ctypes.c_double), vp]
-        if L.gtts_abi_version() != 4:
+        if L.gtts_abi_version() != 5:
             raise RuntimeError("libgradtts_gfx950.so ABI version mismatch")
         _lib = L
         return _lib

@@ -70,6 +70,30 @@ __device__ __forceinline__ void split_bf16(float x, __bf16 &h, __bf16 &l) {
     l = (__bf16)(x - (float)h);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// GTTS_PREC_F16F8: the "f16 + fp8 cross terms" split of an fp32 contraction (conv_mfma.hip, NSPLIT == 3).
+//   x = xh + xl, xh = fp16(x) (RNE, 11 significant bits), xl = x - xh exactly (|xl| <= 2^-12 |x|);  w = wh + wl likewise.
+//   w x  =  wh xh                      one v_mfma_f32_32x32x16_f16 per 16 channels (products of 22 bits: exact in the fp32 accumulate)
+//         + w xl + wl x   (- wl xl)    ONE v_mfma_f32_32x32x64_f8f6f4 per 32 channels: K block 0 = q8(w) . q8(xl 2^S),
+//                                      K block 1 = q8(wl 2^(S+D)) . q8(x 2^-D), q8 = fp8 e4m3 (4 significant bits).
+// The cross terms are 2^-12 of the product, so their 2^-4 relative rounding leaves ~2^-17 per product -- the grade of the bf16x3
+// split (measured on the chip, tools/probe/f8_probe2.hip: 1.3e-5 vs 4.2e-6 relative on a K = 1152 reduction) -- for 2/3 of its
+// MFMA cycles (the fp8 instruction retires twice the K per cycle) and 1.53x its sustained rate under the power cap
+// (tools/probe/f8_probe.hip).  Both fp8 products carry the factor 2^S; instead of the instruction's block scales the fp16 weights are
+// stored pre-multiplied by 2^S (exact) so that the accumulator holds 2^S x the result and the epilogue multiplies by 2^-S (exact).
+// Ranges: fp8 e4m3 tops out at 448 and the conversion instruction returns NaN beyond it (probed), so both operands saturate
+// through v_med3_f32 first: |xl 2^S| <= |x| / 2 -- activations beyond 896 only lose their own cross term (fp16-grade for that
+// element, finite); |x 2^-D| saturates beyond 7168.  Weights: |w| 2^S must stay below the fp16 maximum (|w| < 63).
+constexpr int F8_S = 10;         // common factor 2^S of the two fp8 products and of the fp16 weights
+constexpr int F8_D = 4;          // x enters K block 1 as x 2^-D, wl as wl 2^(S+D)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+__device__ __forceinline__ float f8_sat(float v) { return __builtin_amdgcn_fmed3f(v, -448.0f, 448.0f); }
+// two fp32 -> two fp8 e4m3 (RNE) in the low (hi_word = false) or high half of `old`
+template <bool HI>
+__device__ __forceinline__ int cvt2_fp8(float a, float b, int old) { return __builtin_amdgcn_cvt_pk_fp8_f32(a, b, old, HI); }
+
 // activation load / store through a buffer descriptor (per-lane byte offset + scalar byte offset), fp32 or bf16 storage
 template <typename AT>
 __device__ __forceinline__ float ld_act(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
@@ -187,6 +211,8 @@ struct ConvArgs {
     const float *omask;     // EPI_PLAIN, conv_mfma.hip only: [B][Wout] column mask multiplied into the output (the data gradient
                             // of a masked convolution, train.hip); nullptr: none
     int act_bf16;           // 1: activation tensors are stored as bf16 (GTTS_PREC_BF16_STORE)
+    int f16f8;              // 1: GTTS_PREC_F16F8 -- eligible Block convolutions (conv_f16f8_ok) run the f16 + fp8 split on weights
+                            //    packed in that format; everything else of the plan stays bf16x3 (nsplit == 2)
     // EPI_STATS with the GroupNorm finalize fused in: the last workgroup of a sample to publish its partial sums (an
     // agent-scope ticket per sample) reduces them in a fixed order and writes the per-channel scale / shift.
     unsigned *ticket;       // [B] zero before the launch; reset to zero by the finalizing workgroup.  nullptr: not fused
@@ -206,11 +232,12 @@ struct ConvGeom {
     int kch;    // 16-channel MFMA k-steps per chunk (chunk = 16 * kch input channels)
 };
 // host helper: how a layer is tiled (must match the template instantiations in conv_mfma.hip)
-static inline ConvGeom conv_geom(int mode, int cin, int cout) {
+static inline ConvGeom conv_geom(int mode, int cin, int cout, int f16f8 = 0) {
     ConvGeom g;
     bool wide = cout > 64 && mode != CONV_C7;      // the 7x7 stage (7 taps) only fits LDS with the 64-cout tile
     g.MT = wide ? 128 : 64;
-    g.kch = 1;   // 16-channel chunks: measured faster than 32 (occupancy: 3 workgroups per CU beat fewer barriers)
+    g.kch = f16f8 ? 2 : 1;   // 16-channel chunks: measured faster than 32 (occupancy: 3 workgroups per CU beat fewer barriers);
+                             // the f16 + fp8 split walks 32 (K of the fp8 instruction is 64 = 32 channels x 2 cross terms)
     (void)cin;
     if (mode == CONV_C7) { g.TR = 8; g.nst = 7; g.tps = 7; }
     else if (mode == CONV_DN) { g.TR = 4; g.nst = 3; g.tps = 3; }
@@ -240,6 +267,10 @@ hipError_t launch_conv_ws(const ConvArgs &a, hipStream_t st);
 // conv_up.hip: Upsample with the four output phases computed from one staged tile (fp32 storage, bf16x3)
 bool conv_up4_eligible(const ConvArgs &a);
 hipError_t launch_conv_up4(const ConvArgs &a, hipStream_t st);
+// Block convolutions that take the f16 + fp8 split when the plan's precision is GTTS_PREC_F16F8 (conv_mfma.hip): 3x3, whole
+// 32-channel chunks (a concatenated input splitting on one), mask / GroupNorm prologue, statistics epilogue, and an LDS
+// footprint that leaves two workgroups per CU.  Decides the packing of the layer's weights as well (pack.hip).
+bool conv_f16f8_ok(int mode, int c0, int c1, int cout, int pro, int epi);
 bool conv_small_tiles(int mode, int cout, int Hout, int Wout, int B);   // half-height tiles for launches smaller than the chip
 bool conv_rowpair_stats(int mode, int cout, int Hout, int Wout);        // GroupNorm partial slots per row pair (batch-size independent)
 

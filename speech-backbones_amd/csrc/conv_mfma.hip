@@ -21,7 +21,9 @@
 // loop is straight-line code (unconditional loads from clamped addresses + selects, no exec-mask branches).
 //
 // Precision: NSPLIT == 2 computes hi*hi + hi*lo + lo*hi with fp32 accumulation (error ~2^-17 per product,
-// i.e. fp32-grade: SURVEY.md section 0); NSPLIT == 1 is plain bf16.
+// i.e. fp32-grade: SURVEY.md section 0); NSPLIT == 1 is plain bf16; NSPLIT == 3 is the f16 + fp8 split of GTTS_PREC_F16F8
+// (common.h: fp16 hi*hi on v_mfma_f32_32x32x16_f16 + both cross terms in one v_mfma_f32_32x32x64_f8f6f4 per 32 channels; 3x3 Block
+// convolutions on whole 32-channel chunks only, KCH == 2).
 //
 // Wave tile: (MF x 32) output channels x (2 rows x 32 columns) pixels; a workgroup is WM x WN waves.
 #include "common.h"
@@ -39,8 +41,12 @@
 #ifndef GTTS_DN_WAVES
 #define GTTS_DN_WAVES 2
 #endif
+// the f16 + fp8 split (NSPLIT == 3, GTTS_PREC_F16F8) stages 32-channel chunks: 74-80 KB of LDS per workgroup, two per CU
+#ifndef GTTS_F8_WAVES
+#define GTTS_F8_WAVES 2
+#endif
 #define GTTS_WAVES(MODE) ((MODE) == CONV_DN ? GTTS_DN_WAVES : GTTS_C3_WAVES)
-#define GTTS_WAVES_NS(MODE, NSPLIT) ((MODE) == CONV_DN ? GTTS_DN_WAVES : ((NSPLIT) == 1 ? GTTS_C3_WAVES_BF16 : GTTS_C3_WAVES))
+#define GTTS_WAVES_NS(MODE, NSPLIT) ((MODE) == CONV_DN ? GTTS_DN_WAVES : ((NSPLIT) == 3 ? GTTS_F8_WAVES : ((NSPLIT) == 1 ? GTTS_C3_WAVES_BF16 : GTTS_C3_WAVES)))
 // Diagnostics exist only in -DGTTS_DIAG builds (tools/abexp.sh, tools/trace_conv.py); the product library is compiled
 // without it and the three switches below are then forced off, whatever else is on the command line.
 // GTTS_EXP: timing-only ablations of the main loop (results are WRONG)
@@ -189,6 +195,9 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
     constexpr int AB = (int)sizeof(AT);      // bytes per stored activation
     using C = ConvCfg<MODE, WM, WN, MF, KCH, NF>;
     static_assert(!PRIV || (MODE == CONV_C3 && FULLC && KCH == 1 && MF == 1), "private weight slices: 3x3, whole chunks, one fragment row per wave");
+    static_assert(NSPLIT != 3 || (MODE == CONV_C3 && FULLC && KCH == 2 && !PRIV && sizeof(AT) == 4 && (PRO == PRO_MASK || PRO == PRO_GN)),
+                  "f16 + fp8 split: 3x3 Block convolutions on whole 32-channel chunks, fp32 storage");
+    static_assert(NSPLIT != 3 || (!ConvWdma<MODE, WM, FULLC>::on && !ConvAdbuf<MODE, WM, FULLC>::on), "f16 + fp8 split: plain staging only");
     constexpr int MT = C::MT, TR = C::TR, TC = C::TC, NST = C::NST, TPS = C::TPS, NKG = C::NKG;
     constexpr int HC = C::HC, NPIX = C::NPIX, AITER = C::AITER, WBLK16 = C::WBLK16;
     // single-pass bf16 (NSPLIT == 1) multiplies with the hi halves only: the block's first half ([split][tap][kg][MT] order) is
@@ -444,6 +453,7 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
                 }
             }
             bf16x8 vh, vl;
+            [[maybe_unused]] float vv[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 float v = araw[it][i];
@@ -460,7 +470,9 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
                     v = fmaf(ga, sg, tb[i]) * m;
                     if (!FULLC) v = (inb && i < nval) ? v : 0.f;
                 }
-                if constexpr (NSPLIT > 1) {
+                if constexpr (NSPLIT == 3) {
+                    vv[i] = v;
+                } else if constexpr (NSPLIT > 1) {
                     __bf16 h, l;
                     split_bf16(v, h, l);
                     vh[i] = h;
@@ -469,6 +481,33 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
                     vh[i] = (__bf16)v;           // single-pass bf16: no lo plane (neither computed nor written)
                 }
             }
+            if constexpr (NSPLIT == 3) {
+                // f16 + fp8 split (common.h): hi plane fp16 [kg][pixel][8 ch]; cross-term plane [g][pixel][16 ch] fp8 with
+                // g = plane * 2 + (16-channel half): plane 0 = q8(xl 2^S), plane 1 = q8(x 2^-D); this item owns 8 of the 16 bytes
+                f16x8 fh;
+                int lw[2] = {0, 0}, xw[2] = {0, 0};
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    const _Float16 h0 = (_Float16)vv[i], h1 = (_Float16)vv[i + 1];
+                    fh[i] = h0;
+                    fh[i + 1] = h1;
+                    const float t0 = f8_sat((vv[i] - (float)h0) * (float)(1 << F8_S)), t1 = f8_sat((vv[i + 1] - (float)h1) * (float)(1 << F8_S));
+                    const float u0 = f8_sat(vv[i] * (1.0f / (float)(1 << F8_D))), u1 = f8_sat(vv[i + 1] * (1.0f / (float)(1 << F8_D)));
+                    if (i & 2) { lw[i >> 2] = cvt2_fp8<true>(t0, t1, lw[i >> 2]); xw[i >> 2] = cvt2_fp8<true>(u0, u1, xw[i >> 2]); }
+                    else { lw[i >> 2] = cvt2_fp8<false>(t0, t1, lw[i >> 2]); xw[i >> 2] = cvt2_fp8<false>(u0, u1, xw[i >> 2]); }
+                }
+                if (has) {
+                    const int slot = pr * HC + lc;
+                    dh[kg * NPIX + slot] = __builtin_bit_cast(u32x4, fh);
+                    typedef __attribute__((ext_vector_type(2))) int i32x2;
+                    i32x2 *d8 = reinterpret_cast<i32x2 *>(dl);
+                    i32x2 q0, q1;
+                    q0[0] = lw[0]; q0[1] = lw[1];
+                    q1[0] = xw[0]; q1[1] = xw[1];
+                    d8[(((kg >> 1)) * NPIX + slot) * 2 + (kg & 1)] = q0;
+                    d8[((2 + (kg >> 1)) * NPIX + slot) * 2 + (kg & 1)] = q1;
+                }
+            } else
             if constexpr (ADBUF) {
                 // branch-free (lanes without an item write a scratch slot): keeps the transform in the MFMAs' basic block
                 const int slot = kg * NPIX + pr * HC + lc;
@@ -615,6 +654,43 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
                         po[ni] = (r + 1 + dy) * HC + 1 + dx;
                     } else po[ni] = r * HC;
                 }
+                if constexpr (NSPLIT == 3) {
+                    // 32 channels of one tap: two fp16 k-steps (hi * hi) + one fp8 K = 64 step (both cross terms); the per-accumulator
+                    // order k-step 0, k-step 1, fp8 is the same in every instance of a layer (batch-size independent results)
+                    f16x8 fwh[2][MF], fxh[2][NF];
+                    i32x8 w8[MF], x8[NF];
+#pragma unroll
+                    for (int kc = 0; kc < 2; ++kc) {
+#pragma unroll
+                        for (int mi = 0; mi < MF; ++mi)
+                            fwh[kc][mi] = *reinterpret_cast<const f16x8 *>(&s_wc[(j * NKG + kc * 2 + kg_l) * MT + m0 + mi * 32 + l31]);
+#pragma unroll
+                        for (int ni = 0; ni < NF; ++ni)
+                            fxh[kc][ni] = *reinterpret_cast<const f16x8 *>(&s_xh[(kc * 2 + kg_l) * NPIX + po[ni] + l31]);
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < MF; ++mi) {
+                        const int wi = TPS * NKG * MT + (j * NKG + kg_l * 2) * MT + m0 + mi * 32 + l31;
+                        const u32x4 q0 = s_wc[wi], q1 = s_wc[wi + MT];
+                        w8[mi][0] = (int)q0[0]; w8[mi][1] = (int)q0[1]; w8[mi][2] = (int)q0[2]; w8[mi][3] = (int)q0[3];
+                        w8[mi][4] = (int)q1[0]; w8[mi][5] = (int)q1[1]; w8[mi][6] = (int)q1[2]; w8[mi][7] = (int)q1[3];
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < NF; ++ni) {
+                        const int xi = (kg_l * 2) * NPIX + po[ni] + l31;
+                        const u32x4 q0 = s_xl[xi], q1 = s_xl[xi + NPIX];
+                        x8[ni][0] = (int)q0[0]; x8[ni][1] = (int)q0[1]; x8[ni][2] = (int)q0[2]; x8[ni][3] = (int)q0[3];
+                        x8[ni][4] = (int)q1[0]; x8[ni][5] = (int)q1[1]; x8[ni][6] = (int)q1[2]; x8[ni][7] = (int)q1[3];
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NF; ++ni) {
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh[0][mi], fxh[0][ni], acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh[1][mi], fxh[1][ni], acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8[mi], x8[ni], acc[mi][ni], 0, 0, 0, 0, 0, 0);
+                        }
+                } else
 #pragma unroll
                 for (int kc = 0; kc < KCH; ++kc) {
                     bf16x8 wh[MF], wl[MF], xh[NF], xl[NF];
@@ -714,7 +790,9 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
 #pragma unroll
                 for (int rg = 0; rg < 16; ++rg) {
                     const int col = m0 + mi * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kg_l;   // channel inside the tile
-                    float v = acc[mi][ni][rg] + s_epi[col];
+                    float v;
+                    if constexpr (NSPLIT == 3) v = fmaf(acc[mi][ni][rg], 1.0f / (float)(1 << F8_S), s_epi[col]);   // accumulators hold 2^S x the sum (common.h)
+                    else v = acc[mi][ni][rg] + s_epi[col];
                     if (EPI == EPI_TAIL) {
                         const float y = fmaf(ex[rg], s_epi[MT + col], s_epi[2 * MT + col]);
                         v = fmaf(mish_f(y), m_out, v);
@@ -941,6 +1019,18 @@ static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
     return hipGetLastError();
 }
 
+// See common.h.  The LDS bound keeps two workgroups per CU: one 32-channel activation image (fp16 plane + fp8 plane), one weight
+// stage of three taps, the prologue's per-channel parameters.
+bool conv_f16f8_ok(int mode, int c0, int c1, int cout, int pro, int epi) {
+    const int cin = c0 + c1;
+    if (mode != CONV_C3 || epi != EPI_STATS || (pro != PRO_MASK && pro != PRO_GN)) return false;
+    if (cin % 32 != 0 || (c1 != 0 && c0 % 32 != 0) || cout % 64 != 0) return false;
+    const ConvGeom g = conv_geom(mode, cin, cout, 1);
+    if (cout % g.MT != 0) return false;
+    const int npix = (g.TR + 2) * 34, nkg = 2 * g.kch;
+    return conv_smem_bytes(npix, nkg, g.tps * g.MT * 2 * nkg, cin, pro, g.MT) <= (size_t)80 * 1024;
+}
+
 // Small launches (B = 1, what Grad-TTS/inference.py runs): a 3x3 layer whose regular tiling yields fewer than GTTS_SMALL_WGS
 // workgroups (half the CUs) is tiled with half-height tiles (128 x (2 x 32) / 64 x (4 x 32)): twice the workgroups, each half as long.
 // The kernel is latency-bound in that regime (one workgroup per CU, one wave per SIMD), so the time roughly halves.
@@ -967,6 +1057,17 @@ int conv_nparts(int mode, int cout, int Hout, int Wout) {
 template <int MODE, int WM, int WN, int MF, int PRO, int EPI>
 static hipError_t launch_prec(const ConvArgs &a, hipStream_t st) {
     const bool fullc = a.cin % 16 == 0 && (a.c1 == 0 || a.c0 % 16 == 0);
+    if constexpr (MODE == CONV_C3 && EPI == EPI_STATS && (PRO == PRO_MASK || PRO == PRO_GN)) {
+        // GTTS_PREC_F16F8: the layer's weights are packed in the f16 + fp8 format exactly when conv_f16f8_ok says so (plan.hip)
+        if (a.f16f8 && conv_f16f8_ok(MODE, a.c0, a.c1, a.cout, PRO, EPI)) {
+            if (a.act_bf16 || a.nsplit != 2) return hipErrorInvalidValue;
+            if (conv_small_tiles(MODE, a.cout, a.Hout, a.Wout, a.B)) {      // half-height tiles, as below
+                if constexpr (WM == 2) return launch_cfg<MODE, 4, 1, 1, 2, PRO, EPI, 3, 1, float, 2, 0>(a, st);
+                else return launch_cfg<MODE, 2, 2, 1, 2, PRO, EPI, 3, 1, float, 2, 0>(a, st);
+            }
+            return launch_cfg<MODE, WM, WN, MF, 2, PRO, EPI, 3, 1, float, 2, 0>(a, st);
+        }
+    }
     if constexpr (MODE == CONV_C3 && PRO != PRO_IGLU) {
         // half-height tiles for small launches (conv_small_tiles): same cout tile, waves re-arranged to 32 channels x 2 rows
         if (fullc && !a.act_bf16 && a.nsplit > 1 && conv_small_tiles(MODE, a.cout, a.Hout, a.Wout, a.B)) {

@@ -1,5 +1,6 @@
 // pack.hip -- one-time re-layout of the estimator parameters into the packed blob (device side).
 //
+// (CONV_C3 | 32: the f16 + fp8 format of GTTS_PREC_F16F8, 32-channel chunks -- see pack_conv_element and common.h.)
 // Convolution weights become bf16 (hi, lo) pairs in MFMA-fragment order, one contiguous block per
 // (phase, 16-channel chunk, stage, cout tile); inside a block the order is the LDS image of conv_mfma.hip:
 //     [split: hi|lo][tap][kgroup 0..2*kch-1][cout-in-tile MT][8 channels]      (chunk = 16*kch input channels)
@@ -12,8 +13,10 @@
 namespace gtts {
 
 // one (hi, lo) element pair t of one convolution's packed blob
-__device__ __forceinline__ void pack_conv_element(const float *__restrict__ w, __bf16 *__restrict__ dst, int mode, int cin, int cout,
+__device__ __forceinline__ void pack_conv_element(const float *__restrict__ w, __bf16 *__restrict__ dst, int mode_in, int cin, int cout,
                                                   int MT, int nst, int tps, int nchunk, int ncot, int nkg, size_t t) {
+    const int mode = mode_in & 31;
+    const bool f16f8 = (mode_in & 32) != 0;      // CONV_C3 | 32: the f16 + fp8 format of GTTS_PREC_F16F8
     // decode t -> (phase, chunk, stage, cot, tap, kg, m, i)
     size_t r = t;
     const int i = r % 8; r /= 8;
@@ -49,10 +52,25 @@ __device__ __forceinline__ void pack_conv_element(const float *__restrict__ w, _
                 v = w[(((size_t)ci * cout + co) * 4 + ky) * 4 + kx];
         }
     }
-    __bf16 hi, lo;
-    split_bf16(v, hi, lo);
     const size_t blk = (((size_t)phase * nchunk + chunk) * nst + stage) * ncot + cot;
     const size_t blk_elems = (size_t)tps * MT * 16 * nkg;                    // bf16 elements per block
+    if (f16f8) {
+        // GTTS_PREC_F16F8 (common.h): split 0 = fp16(w 2^S) in the bf16 hi plane's place; split 1 = [tap][g 0..3][cout][16 bytes] fp8:
+        // g = plane * 2 + half, half = 16-channel half of the 32-channel chunk; plane 0 = q8(w), plane 1 = q8(wl 2^(S+D)),
+        // wl = w - hi 2^-S.  (nkg == 4: kg * 8 + i is the channel inside the chunk.)
+        const _Float16 h = (_Float16)(v * (float)(1 << F8_S));
+        const float wl = v - (float)h * (1.0f / (float)(1 << F8_S));
+        reinterpret_cast<_Float16 *>(dst)[blk * blk_elems + (((size_t)(0 * tps + tap) * nkg + kg) * MT + m) * 8 + i] = h;
+        const int cc = kg * 8 + i, half = cc >> 4, j = cc & 15;
+        unsigned char *d8 = reinterpret_cast<unsigned char *>(dst) + (blk * blk_elems + (size_t)tps * nkg * MT * 8) * 2;
+        const int q0 = __builtin_amdgcn_cvt_pk_fp8_f32(f8_sat(v), 0.f, 0, false);
+        const int q1 = __builtin_amdgcn_cvt_pk_fp8_f32(f8_sat(wl * (float)(1 << (F8_S + F8_D))), 0.f, 0, false);
+        d8[(((size_t)tap * nkg + half) * MT + m) * 16 + j] = (unsigned char)(q0 & 0xff);
+        d8[(((size_t)tap * nkg + 2 + half) * MT + m) * 16 + j] = (unsigned char)(q1 & 0xff);
+        return;
+    }
+    __bf16 hi, lo;
+    split_bf16(v, hi, lo);
     const size_t e_hi = blk * blk_elems + (((size_t)(0 * tps + tap) * nkg + kg) * MT + m) * 8 + i;
     const size_t e_lo = blk * blk_elems + (((size_t)(1 * tps + tap) * nkg + kg) * MT + m) * 8 + i;
     dst[e_hi] = hi;
@@ -75,7 +93,7 @@ __global__ void pack_conv_batch_kernel(const PackDesc *__restrict__ descs) {
 }
 
 static void pack_geometry(int mode, int cin, int cout, PackDesc &d) {
-    ConvGeom g = conv_geom(mode & 15, cin, cout);
+    ConvGeom g = conv_geom(mode & 15, cin, cout, (mode & 32) ? 1 : 0);
     d.mode = mode; d.cin = cin; d.cout = cout;
     d.nkg = 2 * g.kch;
     d.nchunk = (cin + 8 * d.nkg - 1) / (8 * d.nkg);

@@ -45,6 +45,8 @@ int set_error(int code, const char *msg) { g_err = msg; return code; }     // fo
     } while (0)
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+struct gtts_plan;
+static int plan_nsplit(const gtts_plan *p);      // 2: hi/lo operand planes (BF16X3, and everything F16F8 leaves on it), 1: plain bf16
 
 // ------------------------------------------------------------------------------------------------ plan data
 enum TensorKind { TK_ACT, TK_PERB, TK_PART, TK_APART, TK_BYTES_PERB, TK_ROWS };
@@ -88,7 +90,7 @@ struct ParamDesc {
     int rank;
     int dims[4];
     size_t off;      // blob byte offset of the packed / copied form
-    int pack;        // 0 copy fp32, 1 conv C3, 2 conv DN, 3 conv UP, 4 conv P1, 5 to_qkv (kv packed + q copy)
+    int pack;        // 0 copy fp32, 1 conv C3, 2 conv DN, 3 conv UP, 4 conv P1, 5 to_qkv (kv packed + q copy), 6 conv C3 in the f16 + fp8 format
     size_t off2;     // to_qkv: fp32 copy of the q rows
     int cin, cout;
 };
@@ -154,7 +156,7 @@ static int add_param(gtts_plan *p, const std::string &name, std::vector<int> dim
     for (int v : dims) n *= (size_t)v;
     switch (pack) {
         case 0: bytes = n * 4; break;
-        case 1: bytes = conv_packed_bytes(CONV_C3, cin, cout); break;
+        case 1: case 6: bytes = conv_packed_bytes(CONV_C3, cin, cout); break;      // (6: cin % 32 == 0, the same bytes in 32-channel chunks)
         case 2: bytes = conv_packed_bytes(CONV_DN, cin, cout); break;
         case 3: bytes = conv_packed_bytes(CONV_UP, cin, cout); break;
         case 4: bytes = conv_packed_bytes(CONV_P1, cin, cout); break;
@@ -194,7 +196,9 @@ static Op blank_op(int kind, const std::string &label) {
 static void add_block(gtts_plan *p, const std::string &pre, const std::string &tname, int src0, int c0, int src1,
                       int c1, int cout, int lvl, int pro, int psc, int psh, int tb_off, int *raw, int *sc, int *sh) {
     const int cin = c0 + c1;
-    add_param(p, pre + "block.0.weight", {cout, cin, 3, 3}, 1, cin, cout);
+    // GTTS_PREC_F16F8: eligible layers keep their weights in the f16 + fp8 format (pack kind 6; same size as kind 1)
+    const bool f8 = p->cfg.precision == GTTS_PREC_F16F8 && conv_f16f8_ok(CONV_C3, c0, c1, cout, pro, EPI_STATS);
+    add_param(p, pre + "block.0.weight", {cout, cin, 3, 3}, f8 ? 6 : 1, cin, cout);
     add_param(p, pre + "block.0.bias", {cout}, 0);
     add_param(p, pre + "block.1.weight", {cout}, 0);
     add_param(p, pre + "block.1.bias", {cout}, 0);
@@ -202,7 +206,7 @@ static void add_block(gtts_plan *p, const std::string &pre, const std::string &t
     int part = add_tensor(p, tname + ".part", TK_PART, p->cfg.groups, lvl);
     p->tensors[part].mode = CONV_C3;
     p->tensors[part].cout = cout;
-    p->tensors[part].ws = p->cfg.conv_ws && conv_ws_eligible(CONV_C3, c0, c1, cout, pro, EPI_STATS, p->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1);
+    p->tensors[part].ws = p->cfg.conv_ws && conv_ws_eligible(CONV_C3, c0, c1, cout, pro, EPI_STATS, plan_nsplit(p));
     *sc = add_tensor(p, tname + ".sc", TK_PERB, cout, 0);
     *sh = add_tensor(p, tname + ".sh", TK_PERB, cout, 0);
     Op c = blank_op(OP_CONV, tname + ".conv");
@@ -343,13 +347,15 @@ extern "C" int gtts_plan_create(const gtts_unet_cfg *cfg, gtts_plan **out) {
     if (cfg->dim <= 0 || cfg->dim % 32 != 0) return fail(GTTS_E_CONFIG, "dim must be a positive multiple of 32 (got %d)", cfg->dim);
     if (cfg->n_feats <= 0 || cfg->n_feats % 4 != 0) return fail(GTTS_E_CONFIG, "n_feats must be a multiple of 4 (got %d)", cfg->n_feats);
     if (cfg->groups != 8) return fail(GTTS_E_CONFIG, "only groups == 8 is supported (got %d)", cfg->groups);
-    if (cfg->precision != GTTS_PREC_BF16X3 && cfg->precision != GTTS_PREC_BF16 && cfg->precision != GTTS_PREC_BF16_STORE)
+    if (cfg->precision != GTTS_PREC_BF16X3 && cfg->precision != GTTS_PREC_BF16 && cfg->precision != GTTS_PREC_BF16_STORE &&
+        cfg->precision != GTTS_PREC_F16F8)
         return fail(GTTS_E_CONFIG, "unknown precision %d", cfg->precision);
     if (cfg->precision == GTTS_PREC_BF16_STORE && cfg->arch != 0)
         return fail(GTTS_E_CONFIG, "bf16 activation storage is implemented for the Grad-TTS decoder (arch 0) only");
     if (cfg->n_spks < 1) return fail(GTTS_E_CONFIG, "n_spks must be >= 1");
     gtts_plan *p = new gtts_plan();
     p->cfg = *cfg;
+    if (p->cfg.precision != GTTS_PREC_BF16X3) p->cfg.conv_ws = 0;      // the persistent kernel exists for the bf16x3 split only
     p->blob_bytes = 0;
     p->nlev = 3;
     const int dim = cfg->dim;
@@ -595,6 +601,8 @@ static std::vector<int> reg_order(const gtts_plan *p) {
     return idx;
 }
 
+static int plan_nsplit(const gtts_plan *p) { return (p->cfg.precision == GTTS_PREC_BF16X3 || p->cfg.precision == GTTS_PREC_F16F8) ? 2 : 1; }
+
 extern "C" int gtts_plan_num_params(const gtts_plan *plan) { return plan ? (int)plan->params.size() : 0; }
 
 extern "C" int gtts_plan_param_info(const gtts_plan *plan, int i, const char **name, int *rank, int dims[4]) {
@@ -630,6 +638,7 @@ extern "C" int gtts_pack_weights(const gtts_plan *plan, const void *const *param
             case 2: HIPCHK(launch_pack_conv(CONV_DN, src, blob + d.off, d.cin, d.cout, st)); break;
             case 3: HIPCHK(launch_pack_conv(CONV_UP, src, blob + d.off, d.cin, d.cout, st)); break;
             case 4: HIPCHK(launch_pack_conv(CONV_P1, src, blob + d.off, d.cin, d.cout, st)); break;
+            case 6: HIPCHK(launch_pack_conv(CONV_C3 | 32, src, blob + d.off, d.cin, d.cout, st)); break;
             case 5:
                 HIPCHK(launch_pack_attn_kv(src, blob + d.off, d.cin, st));
                 HIPCHK(launch_copy_f32(src, (float *)(blob + d.off2), (size_t)128 * d.cin, st));   // q rows 0..127
@@ -796,7 +805,7 @@ static inline float *tptr(const RunCtx &c, int id) { return id < 0 ? nullptr : (
 
 static int run_ops(const RunCtx &c) {
     gtts_plan *p = c.p;
-    const int F = p->cfg.n_feats, nsplit = p->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1;
+    const int F = p->cfg.n_feats, nsplit = plan_nsplit(p);
     const int abf = p->cfg.precision == GTTS_PREC_BF16_STORE ? 1 : 0;
     for (size_t oi = 0; oi < p->ops.size(); ++oi) {
         const Op &o = p->ops[oi];
@@ -835,6 +844,7 @@ static int run_ops(const RunCtx &c) {
                 a.groups = p->cfg.groups;
                 a.eh = tptr(c, o.eh); a.esc = tptr(c, o.esc); a.esh = tptr(c, o.esh); a.eres = tptr(c, o.eres);
                 a.nsplit = nsplit;
+                a.f16f8 = p->cfg.precision == GTTS_PREC_F16F8 ? 1 : 0;
                 a.use_ws = p->cfg.conv_ws;
                 a.act_bf16 = abf;
                 if (o.epi == EPI_STATS && o.gn_op >= 0 && !o.use_ref) {          // GroupNorm finalize rides in the epilogue
@@ -1375,7 +1385,7 @@ extern "C" int gtts_log_prior(const float *mu_x, const float *y, float *log_prio
 // ------------------------------------------------------------------------------------------------ measurement
 // the template instance launch_conv picks (conv_mfma.hip: launch_prec / launch_cfg), as rocprofv3 prints it
 static std::string conv_kernel_name(int mode, int cin, int cout, int pro, int epi, int nsplit, bool abf, bool small, bool ws, int B, int Ho,
-                                    int Wo, int groups) {
+                                    int Wo, int groups, bool f8 = false) {
     const bool wide = cout > 64;
     if (ws) {      // conv_ws.hip (launch_ws_pro)
         char wb[128];
@@ -1385,7 +1395,8 @@ static std::string conv_kernel_name(int mode, int cin, int cout, int pro, int ep
         return wb;
     }
     if (mode == CONV_UP && nsplit == 2 && !abf && cin % 16 == 0 && pro == PRO_MASK && epi == EPI_PLAIN) return "gtts::conv_up4_kernel";   // conv_up.hip
-    const int kch = conv_geom(mode, cin, cout).kch;
+    const int kch = conv_geom(mode, cin, cout, f8 ? 1 : 0).kch;
+    if (f8) nsplit = 3;
     const bool fullc = cin % 16 == 0;
     int wm, wn, mf;
     if (mode == CONV_DN) { wm = 2; wn = 2; mf = wide ? 2 : 1; }
@@ -1435,10 +1446,11 @@ extern "C" int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, con
                 fl = 2.0 * B * o.cout * cin * taps * Ho * Wo;
                 by = ab * B * (cin * Hi * Wi + o.cout * Ho * Wo);
                 if (o.epi == EPI_TAIL || o.epi == EPI_ATTN) by += ab * B * o.cout * Ho * Wo;
-                s_kernel = conv_kernel_name(o.mode, o.c0 + o.c1, o.cout, o.pro, o.epi, plan->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1,
+                s_kernel = conv_kernel_name(o.mode, o.c0 + o.c1, o.cout, o.pro, o.epi, plan_nsplit(plan),
                                             plan->cfg.precision == GTTS_PREC_BF16_STORE, conv_small_tiles(o.mode, o.cout, Ho, Wo, B),
-                                            plan->cfg.conv_ws && conv_ws_eligible(o.mode, o.c0, o.c1, o.cout, o.pro, o.epi, plan->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1),
-                                            B, (int)Ho, (int)Wo, plan->cfg.groups);
+                                            plan->cfg.conv_ws && conv_ws_eligible(o.mode, o.c0, o.c1, o.cout, o.pro, o.epi, plan_nsplit(plan)),
+                                            B, (int)Ho, (int)Wo, plan->cfg.groups,
+                                            plan->cfg.precision == GTTS_PREC_F16F8 && conv_f16f8_ok(o.mode, o.c0, o.c1, o.cout, o.pro, o.epi));
                 break;
             }
             case OP_GNFIN: s_kernel = "gtts::gn_finalize_kernel"; break;
@@ -1455,9 +1467,9 @@ extern "C" int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, con
             case OP_ACTX: {
                 char nb[96];
                 if (attn_head_per_wave(o.C))
-                    snprintf(nb, sizeof nb, "gtts::attn_ctx64_kernel<%d, %s>", plan->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1, abf ? "__bf16" : "float");
+                    snprintf(nb, sizeof nb, "gtts::attn_ctx64_kernel<%d, %s>", plan_nsplit(plan), abf ? "__bf16" : "float");
                 else
-                    snprintf(nb, sizeof nb, "gtts::attn_ctx_kernel<%d, %d, %s, 2>", plan->cfg.precision == GTTS_PREC_BF16X3 ? 2 : 1, o.C % 32 == 0 ? 1 : 0,
+                    snprintf(nb, sizeof nb, "gtts::attn_ctx_kernel<%d, %d, %s, 2>", plan_nsplit(plan), o.C % 32 == 0 ? 1 : 0,
                              abf ? "__bf16" : "float");
                 s_kernel = nb;
                 fl = 2.0 * B * Hi * Wi * (256.0 * o.C + 128.0 * 32);

@@ -193,7 +193,7 @@ class GradLogPEstimator2d(BaseModule):
         """'bf16x3' (default, fp32-grade), 'bf16' (single bf16 MFMA, fp32 activations) or 'bf16_store' (BASELINE
         config 3 as written: bf16 MFMA and bf16 activation storage)."""
         be = backend()
-        self._precision = {"bf16x3": be.PREC_BF16X3, "bf16": be.PREC_BF16, "bf16_store": be.PREC_BF16_STORE}[precision]
+        self._precision = {"bf16x3": be.PREC_BF16X3, "bf16": be.PREC_BF16, "bf16_store": be.PREC_BF16_STORE, "f16f8": be.PREC_F16F8}[precision]
         self._hip_plan = None
         self.invalidate_packed()
 

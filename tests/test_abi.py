@@ -106,7 +106,7 @@ def test_abi_contract_surface():
     compiled into the product library (no GTTS_SKIP_OPS / trace entry points)."""
     S = pkg()
     L = S._lib.lib()
-    assert L.gtts_abi_version() == 4
+    assert L.gtts_abi_version() == 5
     p = S.Plan(streams=0)
     assert L.gtts_plan_set_streams(p._h, None, 0) == 0
     assert L.gtts_plan_set_streams(p._h, None, 3) != 0            # null stream array

@@ -57,7 +57,7 @@ both_convs = pytest.mark.parametrize("conv_ws", [False, True], ids=["conv_mfma",
 
 # ------------------------------------------------------------------------------------------------ library
 def test_native_library_is_loaded(S):
-    assert S._lib.lib().gtts_abi_version() == 4
+    assert S._lib.lib().gtts_abi_version() == 5
     import os
     assert os.path.exists(S._lib.LIB_PATH)
 
