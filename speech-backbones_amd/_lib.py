@@ -266,7 +266,7 @@ class Plan:
         2 with conv_ws (8 + 8 utterances fill the chip in whole rounds of persistent workgroups)."""
         if conv_ws is None:
             conv_ws = int(dim) >= 128
-        conv_ws = bool(conv_ws) and int(precision) == PREC_BF16X3
+        conv_ws = bool(conv_ws) and int(precision) in (PREC_BF16X3, PREC_F16F8)
         self._kw = dict(dim=dim, n_feats=n_feats, n_spks=n_spks, spk_emb_dim=spk_emb_dim, groups=groups,
                         pe_scale=pe_scale, beta_min=beta_min, beta_max=beta_max, precision=precision,
                         keep_intermediates=keep_intermediates, arch=arch, dim_cond=dim_cond, use_ref_t=use_ref_t,

@@ -260,7 +260,7 @@ hipError_t launch_conv(int mode, const ConvArgs &a, hipStream_t st);
 #ifndef GTTS_WS
 #define GTTS_WS 1
 #endif
-bool conv_ws_eligible(int mode, int c0, int c1, int cout, int pro, int epi, int nsplit);
+bool conv_ws_eligible(int mode, int c0, int c1, int cout, int pro, int epi, int nsplit, int f16f8 = 0);
 int conv_ws_nparts(int cout, int Hout, int Wout);      // GroupNorm partial slots per sample it writes (one per 32-frame x 5-row block)
 bool conv_ws_small(int cout, int groups, int Hout, int Wout, int B);   // the launch takes the three-wave workgroup form (same arithmetic)
 hipError_t launch_conv_ws(const ConvArgs &a, hipStream_t st);

@@ -1106,7 +1106,7 @@ static hipError_t launch_prec(const ConvArgs &a, hipStream_t st) {
 hipError_t launch_conv(int mode, const ConvArgs &a, hipStream_t st) {
     const bool wide = a.cout > 64;
     // Block convolutions on whole 16-channel chunks: the persistent wave-specialised kernel (conv_ws.hip)
-    if (a.use_ws && conv_ws_eligible(mode, a.c0, a.c1, a.cout, a.pro, a.epi, a.nsplit)) return launch_conv_ws(a, st);
+    if (a.use_ws && conv_ws_eligible(mode, a.c0, a.c1, a.cout, a.pro, a.epi, a.nsplit, a.f16f8)) return launch_conv_ws(a, st);
     switch (mode) {
         case CONV_C3:
             if (a.epi == EPI_PLAIN) {          // DiffVC RefBlock convolutions (InstanceNorm statistics are a separate pass)

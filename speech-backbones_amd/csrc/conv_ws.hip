@@ -67,7 +67,7 @@ extern "C" int gtts_debug_trace_ws(unsigned long long *dst, int n) {
 
 namespace gtts {
 
-template <int WM, int WN, int MF, int NF>
+template <int WM, int WN, int MF, int NF, int NKGT = 2>
 struct WsCfg {
     static constexpr int NCW = WM * WN;          // consumer waves: 4, or 1 in the small-launch form
     static constexpr int NPW = NCW == 1 ? 2 : NCW;   // producer waves (small form: a 32-channel consumer tile takes 4.3k cycles per
@@ -77,24 +77,32 @@ struct WsCfg {
     static constexpr int TR = WN * NF;           // output rows per workgroup
     static constexpr int HR = TR + 2, HC = 34;   // halo tile
     static constexpr int NPIX = HR * HC;
-    static constexpr int NKG = 2;                // 8-channel groups per 16-channel chunk
+    static constexpr int NKG = NKGT;             // 8-channel groups per chunk: 2 (16 channels), or 4 (32) for the f16 + fp8 split
     static_assert((NCW == 4 && MF == 2) || (NCW == 1 && MF == 1), "four consumer waves of 64 channels, or one of 32");
 };
 
-static inline size_t ws_smem_bytes(int npix, int nsplit, int ring, int cin, int pro, int mt, int mf, int ncw) {
-    const size_t cpad = (size_t)((cin + 15) / 16) * 16;
-    return (size_t)ring * nsplit * 2 * npix * 16 + (pro == PRO_GN ? (size_t)2 * 3 * cpad * 4 : 0) + (size_t)2 * ncw * mf * 8 * 4 +
+// nsplit planes (1: hi; 2: hi + lo, or fp16 hi + fp8 cross-term operands) of nkg 8-channel groups per ring slot
+static inline size_t ws_smem_bytes(int npix, int nsplit, int ring, int cin, int pro, int mt, int mf, int ncw, int nkg = 2) {
+    const size_t cpad = (size_t)((cin + 31) / 32) * 32;
+    return (size_t)ring * nsplit * nkg * npix * 16 + (pro == PRO_GN ? (size_t)2 * 3 * cpad * 4 : 0) + (size_t)2 * ncw * mf * 8 * 4 +
            (size_t)2 * mt * 4;
 }
 
+// NSPLIT == 3: the f16 + fp8 split of GTTS_PREC_F16F8 (common.h) on 32-channel chunks: plane 0 of an image holds fp16 hi values
+// [kg 0..3][pixel][8 channels], plane 1 the fp8 cross-term operands [g = plane * 2 + half][pixel][16 channels]; the consumers issue
+// two fp16 k-steps and one fp8 K = 64 step per tap (2/3 of the bf16x3 MFMA cycles, 1.53x its sustained rate).
 template <int WM, int WN, int MF, int NF, int PRO, int NSPLIT, typename AT, int RING>
 __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_kernel(const ConvArgs a) {
-    using C = WsCfg<WM, WN, MF, NF>;
+    constexpr bool F8 = NSPLIT == 3;
+    using C = WsCfg<WM, WN, MF, NF, F8 ? 4 : 2>;
     constexpr int AB = (int)sizeof(AT);
     constexpr int MT = C::MT, TR = C::TR, HC = C::HC, NPIX = C::NPIX, NKG = C::NKG, NCW = C::NCW;
+    constexpr int CH = 8 * NKG;                      // input channels per chunk (ring item)
+    constexpr int NPL = F8 ? 2 : NSPLIT;             // planes per image
     constexpr int NCT = NCW * 64, NPT = C::NPW * 64;   // consumer / producer threads
     constexpr int PLANE16 = NKG * NPIX;              // 16-byte units of one plane (hi or lo) of an image
-    constexpr int IMG16 = NSPLIT * PLANE16;          // ... of one ring slot
+    constexpr int IMG16 = NPL * PLANE16;             // ... of one ring slot
+    static_assert(!F8 || (AB == 4 && RING == 2), "f16 + fp8 split: fp32 storage, two 32-channel images");
     constexpr int D = RING - 1;                      // producers run D chunks ahead
     // packed weight block (chunk, stage, cout tile of the PACKING: 128 channels for cout > 64): [split][tap][kg][MTP] x 16 B
     const int MTP = a.cout > 64 ? 128 : 64;
@@ -103,7 +111,7 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4 *s_img = reinterpret_cast<u32x4 *>(smem);                      // [RING][split][kg][NPIX]
-    const int cpad = a.nchunk * 16;
+    const int cpad = a.nchunk * CH;
     float *s_par = reinterpret_cast<float *>(s_img + RING * IMG16);      // PRO_GN: [2 (tile parity)][3][cpad] scale, shift, time bias
     float *s_red = s_par + (PRO == PRO_GN ? 2 * 3 * cpad : 0);           // [2 (tile parity)][NCW waves][MF][4 octets][2]
     float *s_epi = s_red + 2 * NCW * MF * 8;                             // [2 (tile parity)][MT] bias
@@ -187,8 +195,223 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
                 w[mi] = __builtin_bit_cast(bf16x8, v);
             }
         };
+        // ------------------------------------------------------------ tile epilogue: bias, store, GroupNorm partial sums
+        auto ws_epilogue = [&](int par) {
+                const int y0 = tl.ty * TR + wn * NF, ox = tl.tx * 32 + l31;
+                const int out_bytes = a.cout * HW * AB;
+                const __amdgpu_buffer_rsrc_t rs_out =
+                    uniform_rsrc(reinterpret_cast<AT *>(a.out) + (size_t)tl.b * a.cout * HW, out_bytes);
+                const int ch0 = tl.cot * MT + m0;
+                const bool col_ok = ox < a.Wout;
+                float st1[MF][4], st2[MF][4];
+#pragma unroll
+                for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { st1[mi][q] = 0.f; st2[mi][q] = 0.f; }
+                const float *bias_l = s_epi + par * MT + m0 + 4 * kg_l;
+                // (Measured and dropped: a 4 x 4 transpose inside every lane quad -- DPP exchanges + bit-selects -- so that a lane
+                // holds four consecutive frames of one channel and stores 16 bytes.  A quarter of the store instructions, but
+                // each then touches 8 channel rows instead of 2: epilogue 12.9k vs 9.9k cycles per 128-channel tile.)
+#pragma unroll
+                for (int mi = 0; mi < MF; ++mi) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float bv[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) bv[i] = bias_l[mi * 32 + 8 * q + i];
+                        const int soff = (ch0 + mi * 32 + 8 * q) * HW * AB;
+#pragma unroll
+                        for (int ni = 0; ni < NF; ++ni) {
+                            const int oy = y0 + ni;
+                            if (oy >= a.Hout) continue;
+                            float r[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                if constexpr (F8) r[i] = fmaf(acc[mi][ni][4 * q + i], 1.0f / (float)(1 << F8_S), bv[i]);   // accumulators hold 2^S x the sum (common.h)
+                                else r[i] = acc[mi][ni][4 * q + i] + bv[i];
+                            }
+                            if (col_ok) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    st1[mi][q] += r[i];
+                                    st2[mi][q] = fmaf(r[i], r[i], st2[mi][q]);
+                                }
+                                const int voff = (oy * a.Wout + ox + 4 * kg_l * HW) * AB;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) st_act<AT>(r[i], rs_out, voff, soff + i * HW * AB);
+                            }
+                        }
+                    }
+                }
+                constexpr int V = 8 * MF;
+                float vals[V], tot[V / 4];
+#pragma unroll
+                for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        vals[mi * 4 + q] = st1[mi][q];
+                        vals[4 * MF + mi * 4 + q] = st2[mi][q];
+                    }
+                wave_sums_transposed<V>(vals, tot);
+                if ((lane & 15) == 0) {
+                    const int r = lane >> 4;
+#pragma unroll
+                    for (int kk = 0; kk < V / 4; ++kk) {
+                        const int vi = kk + (V / 4) * (r & 1) + (V / 2) * (r >> 1);
+                        const int which = vi / (4 * MF), mi = (vi % (4 * MF)) >> 2, q = vi & 3;
+                        s_red[par * (NCW * MF * 8) + ((wave * MF + mi) * 4 + q) * 2 + which] = tot[kk];
+                    }
+                }
+        };
         lds_barrier();                                              // (P) prologue barrier: s_par of tile 0 is written
         int k = 0, cc = 0, slot = 0;
+        if constexpr (F8) {
+            // ---------------------------------------------------------------- f16 + fp8 consumer loop (32 channels per item)
+            // A tap is three passes over the MF x NF accumulators: fp16 k-step 0 (channels 0-15), fp16 k-step 1 (16-31), fp8 (both
+            // cross terms of all 32 channels) -- per accumulator always in this order, in every form of the kernel.  Registers: the
+            // weight fragments of the tap (wa, wb: fp16 k-steps; w8: fp8) are reloaded for the NEXT tap as soon as their last MFMA
+            // has issued (>= 20 MFMAs ahead of their next use); activation fragments are read from LDS one pass ahead.
+            f16x8 wa[MF], wb[MF], xa[NF], xb[NF];
+            i32x8 w8[MF];
+            constexpr int NH = (NF + 1) / 2 + (NF > 2 ? 0 : 0);      // fp8 B fragments are fetched in two groups: [0, NH) and [NH, NF)
+            u32x4 x8a[NH][2], x8b[NF - NH > 0 ? NF - NH : 1][2];
+            const int w_lane8 = (kg_l * 2 * MTP + m0 + l31) * 16;    // fp8 segments: g = kg_l * 2 + q
+            auto wload_h = [&](f16x8 &w, int mi, int kc, int chunk, int stage, int tap, int cot) {
+                const int blk = (chunk * 3 + stage) * ncotp + cot / cpp;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+                    rsw, w_lane + ((cot % cpp) * MT + mi * 32) * 16, blk * (WBLK16 * 16) + ((tap * NKG + kc * 2) * MTP) * 16, 0);
+                w = __builtin_bit_cast(f16x8, v);
+            };
+            auto wload_8 = [&](i32x8 &w, int mi, int chunk, int stage, int tap, int cot) {
+                const int blk = (chunk * 3 + stage) * ncotp + cot / cpp;
+                const int so = blk * (WBLK16 * 16) + (((3 + tap) * NKG) * MTP) * 16;
+                const int vo = w_lane8 + ((cot % cpp) * MT + mi * 32) * 16;
+                const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rsw, vo, so, 0);
+                const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rsw, vo, so + MTP * 16, 0);
+                w[0] = (int)q0[0]; w[1] = (int)q0[1]; w[2] = (int)q0[2]; w[3] = (int)q0[3];
+                w[4] = (int)q1[0]; w[5] = (int)q1[1]; w[6] = (int)q1[2]; w[7] = (int)q1[3];
+            };
+            auto mk8 = [](const u32x4 (&q)[2]) {
+                i32x8 r;
+                r[0] = (int)q[0][0]; r[1] = (int)q[0][1]; r[2] = (int)q[0][2]; r[3] = (int)q[0][3];
+                r[4] = (int)q[1][0]; r[5] = (int)q[1][1]; r[6] = (int)q[1][2]; r[7] = (int)q[1][3];
+                return r;
+            };
+            for (int i = 0; i < nitems; ++i) {
+                [[maybe_unused]] const unsigned long long tw0 = WT_NOW();
+                lds_barrier();                                      // image of item i is complete; everybody is done with item i - 1
+                [[maybe_unused]] const unsigned long long tw1 = WT_NOW();
+                WT_ADD(0, tw1, tw0);
+                const int par = k & 1;
+                const u32x4 *xh_p = s_img + slot * IMG16 + x_lane;                                  // fp16 plane, k-step 0 (k-step 1: + 2 NPIX)
+                const u32x4 *x8_p = s_img + slot * IMG16 + PLANE16 + x_lane + kg_l * NPIX;          // fp8 plane: g = 2 kg_l (second half: + NPIX)
+                slot = slot + 1 == RING ? 0 : slot + 1;
+                if (cc == 0) {
+                    // a tile starts cold: its first weight fragments are requested here (one exposed round trip per tile)
+#pragma unroll
+                    for (int mi = 0; mi < MF; ++mi) {
+                        wload_h(wa[mi], mi, 0, 0, 0, 0, tl.cot);
+                        wload_h(wb[mi], mi, 1, 0, 0, 0, tl.cot);
+                        wload_8(w8[mi], mi, 0, 0, 0, tl.cot);
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NF; ++ni)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+                    for (int c = tid; c < MT; c += NCT) s_epi[par * MT + c] = a.bias[tl.cot * MT + c];
+                }
+#pragma unroll
+                for (int ni = 0; ni < NF; ++ni) xa[ni] = *reinterpret_cast<const f16x8 *>(xh_p + ni * HC);
+                const bool last_c = cc + 1 == nchunk;
+                const int ncn = last_c ? cc : cc + 1;               // (the last chunk re-requests its own first tap: never used)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int st = 0; st < 3; ++st) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const bool last_t = st == 2 && j == 2;
+                        const int nst = j == 2 ? st + 1 : st, nj = j == 2 ? 0 : j + 1;      // next tap inside the chunk
+                        const int nch = last_t ? ncn : cc, ns = last_t ? 0 : nst, nt = last_t ? 0 : nj;
+                        // ---- pass A: fp16 k-step 0; fetch k-step 1's activation fragments
+#pragma unroll
+                        for (int ni = 0; ni < NF; ++ni) xb[ni] = *reinterpret_cast<const f16x8 *>(xh_p + 2 * NPIX + (ni + st) * HC + j);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int mi = 0; mi < MF; ++mi) {
+#pragma unroll
+                            for (int ni = 0; ni < NF; ++ni)
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[mi], xa[ni], acc[mi][ni], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            wload_h(wa[mi], mi, 0, nch, ns, nt, tl.cot);          // dead: request the next tap's
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        // ---- pass B: fp16 k-step 1; fetch the first group of fp8 fragments
+#pragma unroll
+                        for (int ni = 0; ni < NH; ++ni) {
+                            x8a[ni][0] = x8_p[(ni + st) * HC + j];
+                            x8a[ni][1] = x8_p[NPIX + (ni + st) * HC + j];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int mi = 0; mi < MF; ++mi) {
+#pragma unroll
+                            for (int ni = 0; ni < NF; ++ni)
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[mi], xb[ni], acc[mi][ni], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            wload_h(wb[mi], mi, 1, nch, ns, nt, tl.cot);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        // ---- pass C1: fp8 on the first group; fetch the second group
+                        if constexpr (NF > NH) {
+#pragma unroll
+                            for (int ni = NH; ni < NF; ++ni) {
+                                x8b[ni - NH][0] = x8_p[(ni + st) * HC + j];
+                                x8b[ni - NH][1] = x8_p[NPIX + (ni + st) * HC + j];
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int ni = 0; ni < NH; ++ni) {
+                            const i32x8 b8 = mk8(x8a[ni]);
+#pragma unroll
+                            for (int mi = 0; mi < MF; ++mi)
+                                acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8[mi], b8, acc[mi][ni], 0, 0, 0, 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        // ---- pass C2: fp8 on the second group; fetch the next tap's k-step 0 fragments (same image)
+                        if (!last_t) {
+#pragma unroll
+                            for (int ni = 0; ni < NF; ++ni) xa[ni] = *reinterpret_cast<const f16x8 *>(xh_p + (ni + nst) * HC + nj);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (NF > NH) {
+#pragma unroll
+                            for (int ni = NH; ni < NF; ++ni) {
+                                const i32x8 b8 = mk8(x8b[ni - NH]);
+#pragma unroll
+                                for (int mi = 0; mi < MF; ++mi)
+                                    acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8[mi], b8, acc[mi][ni], 0, 0, 0, 0, 0, 0);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int mi = 0; mi < MF; ++mi) wload_8(w8[mi], mi, nch, ns, nt, tl.cot);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                [[maybe_unused]] const unsigned long long tw2 = WT_NOW();
+                WT_ADD(1, tw2, tw1);
+                WT_ADD(3, 1ull, 0ull);
+                if (!last_c) { ++cc; continue; }
+                ws_epilogue(par);
+                cc = 0;
+                ++k;
+                tl = decode(k);
+                WT_ADD(2, WT_NOW(), tw2);
+            }
+        } else
         for (int i = 0; i < nitems; ++i) {
             [[maybe_unused]] const unsigned long long tw0 = WT_NOW();
             lds_barrier();                                          // image of item i is complete; everybody is done with item i - 1
@@ -292,71 +515,7 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
             WT_ADD(3, 1ull, 0ull);
             if (!last_c) { ++cc; continue; }
 
-            // ------------------------------------------------------------ tile epilogue: bias, store, GroupNorm partial sums
-            {
-                const int y0 = tl.ty * TR + wn * NF, ox = tl.tx * 32 + l31;
-                const int out_bytes = a.cout * HW * AB;
-                const __amdgpu_buffer_rsrc_t rs_out =
-                    uniform_rsrc(reinterpret_cast<AT *>(a.out) + (size_t)tl.b * a.cout * HW, out_bytes);
-                const int ch0 = tl.cot * MT + m0;
-                const bool col_ok = ox < a.Wout;
-                float st1[MF][4], st2[MF][4];
-#pragma unroll
-                for (int mi = 0; mi < MF; ++mi)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { st1[mi][q] = 0.f; st2[mi][q] = 0.f; }
-                const float *bias_l = s_epi + par * MT + m0 + 4 * kg_l;
-                // (Measured and dropped: a 4 x 4 transpose inside every lane quad -- DPP exchanges + bit-selects -- so that a lane
-                // holds four consecutive frames of one channel and stores 16 bytes.  A quarter of the store instructions, but
-                // each then touches 8 channel rows instead of 2: epilogue 12.9k vs 9.9k cycles per 128-channel tile.)
-#pragma unroll
-                for (int mi = 0; mi < MF; ++mi) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float bv[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) bv[i] = bias_l[mi * 32 + 8 * q + i];
-                        const int soff = (ch0 + mi * 32 + 8 * q) * HW * AB;
-#pragma unroll
-                        for (int ni = 0; ni < NF; ++ni) {
-                            const int oy = y0 + ni;
-                            if (oy >= a.Hout) continue;
-                            float r[4];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) r[i] = acc[mi][ni][4 * q + i] + bv[i];
-                            if (col_ok) {
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) {
-                                    st1[mi][q] += r[i];
-                                    st2[mi][q] = fmaf(r[i], r[i], st2[mi][q]);
-                                }
-                                const int voff = (oy * a.Wout + ox + 4 * kg_l * HW) * AB;
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) st_act<AT>(r[i], rs_out, voff, soff + i * HW * AB);
-                            }
-                        }
-                    }
-                }
-                constexpr int V = 8 * MF;
-                float vals[V], tot[V / 4];
-#pragma unroll
-                for (int mi = 0; mi < MF; ++mi)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        vals[mi * 4 + q] = st1[mi][q];
-                        vals[4 * MF + mi * 4 + q] = st2[mi][q];
-                    }
-                wave_sums_transposed<V>(vals, tot);
-                if ((lane & 15) == 0) {
-                    const int r = lane >> 4;
-#pragma unroll
-                    for (int kk = 0; kk < V / 4; ++kk) {
-                        const int vi = kk + (V / 4) * (r & 1) + (V / 2) * (r >> 1);
-                        const int which = vi / (4 * MF), mi = (vi % (4 * MF)) >> 2, q = vi & 3;
-                        s_red[par * (NCW * MF * 8) + ((wave * MF + mi) * 4 + q) * 2 + which] = tot[kk];
-                    }
-                }
-            }
+            ws_epilogue(par);
             cc = 0;
             ++k;
             tl = decode(k);
@@ -434,7 +593,7 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
                 setup_tile(t);
                 write_params(t, lk & 1);
             }
-            const int cb = lc * 16;
+            const int cb = lc * CH;
             const bool first = cb < a.c0;
             Lc.rs = first ? rs0 : rs1;
             Lc.soff = (first ? cb : cb - a.c0) * HW * AB;
@@ -459,7 +618,7 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
                 const int kg = min(idx / (C::HR * NG), NKG - 1);
                 const int rem = idx - (idx / (C::HR * NG)) * (C::HR * NG);
                 const int pr = rem / NG, g = rem - pr * NG;
-                const int cb = chunk * 16 + kg * 8;
+                const int cb = chunk * CH + kg * 8;
                 float sc[8], sh[8], tb[8];
                 if constexpr (PRO == PRO_GN) {
                     const float4 *q0 = reinterpret_cast<const float4 *>(sp + cb);
@@ -474,6 +633,9 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
                     }
                 }
                 bf16x8 vh[4], vl[4];
+                [[maybe_unused]] f16x8 fh[4];                   // f16 + fp8 split: fp16 hi values of the four frames ...
+                [[maybe_unused]] int lw[4][2], xw[4][2];        // ... and their fp8 operands q8(xl 2^S), q8(x 2^-D): 8 channels = 8 bytes per frame
+                [[maybe_unused]] float tprev[4], uprev[4];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     if (GTTS_WS_EXP != 3) {
@@ -494,7 +656,18 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
                                 const float y = fmaf(v, sc[i], sh[i]);
                                 v = fmaf(mish_f(y), m, tb[i]) * m;
                             }
-                            if constexpr (NSPLIT > 1) {
+                            if constexpr (F8) {
+                                const _Float16 h = (_Float16)v;
+                                fh[j][i] = h;
+                                const float t = f8_sat((v - (float)h) * (float)(1 << F8_S)), u = f8_sat(v * (1.0f / (float)(1 << F8_D)));
+                                if (i & 1) {        // channels (i - 1, i) of frame j -> two fp8 bytes of word i >> 2, half (i >> 1) & 1
+                                    if (i & 2) { lw[j][i >> 2] = cvt2_fp8<true>(tprev[j], t, lw[j][i >> 2]); xw[j][i >> 2] = cvt2_fp8<true>(uprev[j], u, xw[j][i >> 2]); }
+                                    else { lw[j][i >> 2] = cvt2_fp8<false>(tprev[j], t, 0); xw[j][i >> 2] = cvt2_fp8<false>(uprev[j], u, 0); }
+                                } else {
+                                    tprev[j] = t;
+                                    uprev[j] = u;
+                                }
+                            } else if constexpr (NSPLIT > 1) {
                                 __bf16 h, l;
                                 split_bf16(v, h, l);
                                 vh[j][i] = h;
@@ -507,19 +680,37 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
                     // the re-request of channel i may not move ahead of its transform (hipcc otherwise copies the four values
                     // aside and issues all eight loads first): an opaque dependence of the load's offset on the last result
                     int voff = it_goff[it];
-                    if constexpr (NSPLIT > 1) asm volatile("" : "+v"(voff) : "v"(vl[0][i]), "v"(vl[1][i]), "v"(vl[2][i]), "v"(vl[3][i]));
+                    if constexpr (F8) asm volatile("" : "+v"(voff) : "v"(fh[0][i]), "v"(fh[1][i]), "v"(fh[2][i]), "v"(fh[3][i]));
+                    else if constexpr (NSPLIT > 1) asm volatile("" : "+v"(voff) : "v"(vl[0][i]), "v"(vl[1][i]), "v"(vl[2][i]), "v"(vl[3][i]));
                     else asm volatile("" : "+v"(voff) : "v"(vh[0][i]), "v"(vh[1][i]), "v"(vh[2][i]), "v"(vh[3][i]));
                     load_one(R, voff, it, i);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (GTTS_WS_EXP != 3) {
                     u32x4 *drow = dst + kg * NPIX + pr * HC + 4 * g;
+                    if constexpr (F8) {
+                        // fp8 plane: [g8 = plane * 2 + (kg >> 1)][pixel][16 bytes]; this item owns bytes 8 (kg & 1) .. + 7 of its pixels
+                        typedef __attribute__((ext_vector_type(2))) int i32x2;
+                        i32x2 *d8 = reinterpret_cast<i32x2 *>(dst + PLANE16) + (((kg >> 1) * NPIX + pr * HC + 4 * g) * 2 + (kg & 1));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (has && 4 * g + j < HC) {
+                                drow[j] = __builtin_bit_cast(u32x4, fh[j]);
+                                i32x2 q0, q1;
+                                q0[0] = lw[j][0]; q0[1] = lw[j][1];
+                                q1[0] = xw[j][0]; q1[1] = xw[j][1];
+                                d8[2 * j] = q0;
+                                d8[2 * (2 * NPIX + j)] = q1;
+                            }
+                        }
+                    } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (has && 4 * g + j < HC) {
                             drow[j] = *reinterpret_cast<u32x4 *>(&vh[j]);
                             if constexpr (NSPLIT > 1) drow[PLANE16 + j] = *reinterpret_cast<u32x4 *>(&vl[j]);
                         }
+                    }
                     }
                 }
             }
@@ -688,12 +879,17 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
 //   * 64 output channels: the same MFMA work needs twice the activation staging and has half the chunks per tile to spread
 //     the epilogue over; a 64 x 640 form of this kernel was level with conv_mfma.hip at 80 x 1024 (300 vs 306 us) and
 //     slower at 40 x 512 (92 vs 79 us).
-bool conv_ws_eligible(int mode, int c0, int c1, int cout, int pro, int epi, int nsplit) {
+bool conv_ws_eligible(int mode, int c0, int c1, int cout, int pro, int epi, int nsplit, int f16f8) {
     const int cin = c0 + c1;
     if (!GTTS_WS || nsplit != 2) return false;
     if (mode != CONV_C3 || epi != EPI_STATS || (pro != PRO_MASK && pro != PRO_GN)) return false;
-    if (cin % 16 != 0 || cin < 32 || (c1 != 0 && c0 % 16 != 0)) return false;
     if (cout % 128 != 0) return false;
+    if (f16f8) {
+        // GTTS_PREC_F16F8: 32-channel chunks (two per tile at least), weights in the f16 + fp8 format (conv_f16f8_ok), two images
+        if (!conv_f16f8_ok(mode, c0, c1, cout, pro, epi) || cin < 64) return false;
+        return ws_smem_bytes(12 * 34, 2, 2, cin, pro, 128, 2, 4, 4) <= (size_t)160 * 1024;
+    }
+    if (cin % 16 != 0 || cin < 32 || (c1 != 0 && c0 % 16 != 0)) return false;
     // three activation images + the per-channel parameters must fit the CU's LDS
     return ws_smem_bytes(12 * 34, 2, 3, cin, pro, 128, 2, 4) <= (size_t)160 * 1024;
 }
@@ -720,8 +916,9 @@ bool conv_ws_small(int cout, int groups, int Hout, int Wout, int B) {
 template <int WM, int WN, int MF, int PRO, int NSPLIT, typename AT>
 static hipError_t launch_ws_ring(ConvArgs &a, hipStream_t st) {
     constexpr int NF = 5;
-    using C = WsCfg<WM, WN, MF, NF>;
-    a.nchunk = a.cin / 16;
+    constexpr int NKG = NSPLIT == 3 ? 4 : 2, RING = NSPLIT == 3 ? 2 : 3, NPL = NSPLIT == 3 ? 2 : NSPLIT;
+    using C = WsCfg<WM, WN, MF, NF, NKG>;
+    a.nchunk = a.cin / (8 * NKG);
     a.tiles_x = (a.Wout + 31) / 32;
     a.tiles_y = (a.Hout + C::TR - 1) / C::TR;
     a.nparts = a.tiles_x * a.tiles_y * WN;
@@ -738,7 +935,7 @@ static hipError_t launch_ws_ring(ConvArgs &a, hipStream_t st) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         n_cu[dev].store(cus, std::memory_order_relaxed);
     }
-    const size_t smem = ws_smem_bytes(C::NPIX, NSPLIT, 3, a.cin, PRO, C::MT, MF, C::NCW);
+    const size_t smem = ws_smem_bytes(C::NPIX, NPL, RING, a.cin, PRO, C::MT, MF, C::NCW, NKG);
     if (smem > (size_t)160 * 1024) return hipErrorInvalidValue;      // (conv_ws_eligible keeps such layers on conv_mfma.hip)
     // persistent workgroups: one per CU for the eight-wave form; the three-wave form fits two per CU (registers: 8 waves)
     const int per_cu = C::NCW == 4 ? 1 : (int)std::min<size_t>(2, (size_t)160 * 1024 / smem);
@@ -746,7 +943,7 @@ static hipError_t launch_ws_ring(ConvArgs &a, hipStream_t st) {
     // (Measured and not kept: persistent workgroups on half of the CUs per launch -- grid 128 with two sub-batch streams, so
     // that the other stream's kernels find free CUs: 7.45 vs 7.48 ms per call; the dispatcher fills the same CUs first.)
     const int grid = (int)std::min<long>(ntiles, (long)cus * per_cu);
-    auto kern = &conv3x3_ws_kernel<WM, WN, MF, NF, PRO, NSPLIT, AT, 3>;
+    auto kern = &conv3x3_ws_kernel<WM, WN, MF, NF, PRO, NSPLIT, AT, RING>;
     static std::atomic<size_t> attr_set[64];
     if (smem > attr_set[dev].load(std::memory_order_relaxed)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -764,6 +961,10 @@ static hipError_t launch_ws_pro(ConvArgs &a, hipStream_t st) {
     else return hipErrorInvalidValue;
 #else
     if (a.act_bf16 || a.nsplit != 2) return hipErrorInvalidValue;
+    if (a.f16f8) {
+        if (conv_ws_small(a.cout, a.groups, a.Hout, a.Wout, a.B)) return launch_ws_ring<1, 1, 1, PRO, 3, float>(a, st);
+        return launch_ws_ring<2, 2, 2, PRO, 3, float>(a, st);
+    }
     if (conv_ws_small(a.cout, a.groups, a.Hout, a.Wout, a.B)) return launch_ws_ring<1, 1, 1, PRO, 2, float>(a, st);
     return launch_ws_ring<2, 2, 2, PRO, 2, float>(a, st);
 #endif
@@ -771,8 +972,8 @@ static hipError_t launch_ws_pro(ConvArgs &a, hipStream_t st) {
 
 hipError_t launch_conv_ws(const ConvArgs &a_in, hipStream_t st) {
     ConvArgs a = a_in;
-    if (!conv_ws_eligible(CONV_C3, a.c0, a.c1, a.cout, a.pro, a.epi, a.nsplit)) return hipErrorInvalidValue;
-    if (a.cin / 16 < 2) return hipErrorInvalidValue;
+    if (!conv_ws_eligible(CONV_C3, a.c0, a.c1, a.cout, a.pro, a.epi, a.nsplit, a.f16f8)) return hipErrorInvalidValue;
+    if (a.cin / (a.f16f8 ? 32 : 16) < 2) return hipErrorInvalidValue;
     return a.pro == PRO_GN ? launch_ws_pro<PRO_GN>(a, st) : launch_ws_pro<PRO_MASK>(a, st);
 }
 

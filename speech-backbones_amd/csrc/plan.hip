@@ -206,7 +206,7 @@ static void add_block(gtts_plan *p, const std::string &pre, const std::string &t
     int part = add_tensor(p, tname + ".part", TK_PART, p->cfg.groups, lvl);
     p->tensors[part].mode = CONV_C3;
     p->tensors[part].cout = cout;
-    p->tensors[part].ws = p->cfg.conv_ws && conv_ws_eligible(CONV_C3, c0, c1, cout, pro, EPI_STATS, plan_nsplit(p));
+    p->tensors[part].ws = p->cfg.conv_ws && conv_ws_eligible(CONV_C3, c0, c1, cout, pro, EPI_STATS, plan_nsplit(p), p->cfg.precision == GTTS_PREC_F16F8);
     *sc = add_tensor(p, tname + ".sc", TK_PERB, cout, 0);
     *sh = add_tensor(p, tname + ".sh", TK_PERB, cout, 0);
     Op c = blank_op(OP_CONV, tname + ".conv");
@@ -355,7 +355,7 @@ extern "C" int gtts_plan_create(const gtts_unet_cfg *cfg, gtts_plan **out) {
     if (cfg->n_spks < 1) return fail(GTTS_E_CONFIG, "n_spks must be >= 1");
     gtts_plan *p = new gtts_plan();
     p->cfg = *cfg;
-    if (p->cfg.precision != GTTS_PREC_BF16X3) p->cfg.conv_ws = 0;      // the persistent kernel exists for the bf16x3 split only
+    if (p->cfg.precision != GTTS_PREC_BF16X3 && p->cfg.precision != GTTS_PREC_F16F8) p->cfg.conv_ws = 0;      // the persistent kernel exists for the fp32-grade splits only
     p->blob_bytes = 0;
     p->nlev = 3;
     const int dim = cfg->dim;
@@ -1390,8 +1390,8 @@ static std::string conv_kernel_name(int mode, int cin, int cout, int pro, int ep
     if (ws) {      // conv_ws.hip (launch_ws_pro)
         char wb[128];
         const bool sm = conv_ws_small(cout, groups, Ho, Wo, B);
-        snprintf(wb, sizeof wb, "gtts::conv3x3_ws_kernel<%d, %d, %d, 5, %d, %d, %s, 3>", sm ? 1 : 2, sm ? 1 : 2, sm ? 1 : 2, pro, nsplit,
-                 abf ? "__bf16" : "float");
+        snprintf(wb, sizeof wb, "gtts::conv3x3_ws_kernel<%d, %d, %d, 5, %d, %d, %s, %d>", sm ? 1 : 2, sm ? 1 : 2, sm ? 1 : 2, pro, f8 ? 3 : nsplit,
+                 abf ? "__bf16" : "float", f8 ? 2 : 3);
         return wb;
     }
     if (mode == CONV_UP && nsplit == 2 && !abf && cin % 16 == 0 && pro == PRO_MASK && epi == EPI_PLAIN) return "gtts::conv_up4_kernel";   // conv_up.hip
@@ -1448,7 +1448,7 @@ extern "C" int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, con
                 if (o.epi == EPI_TAIL || o.epi == EPI_ATTN) by += ab * B * o.cout * Ho * Wo;
                 s_kernel = conv_kernel_name(o.mode, o.c0 + o.c1, o.cout, o.pro, o.epi, plan_nsplit(plan),
                                             plan->cfg.precision == GTTS_PREC_BF16_STORE, conv_small_tiles(o.mode, o.cout, Ho, Wo, B),
-                                            plan->cfg.conv_ws && conv_ws_eligible(o.mode, o.c0, o.c1, o.cout, o.pro, o.epi, plan_nsplit(plan)),
+                                            plan->cfg.conv_ws && conv_ws_eligible(o.mode, o.c0, o.c1, o.cout, o.pro, o.epi, plan_nsplit(plan), plan->cfg.precision == GTTS_PREC_F16F8),
                                             B, (int)Ho, (int)Wo, plan->cfg.groups,
                                             plan->cfg.precision == GTTS_PREC_F16F8 && conv_f16f8_ok(o.mode, o.c0, o.c1, o.cout, o.pro, o.epi));
                 break;

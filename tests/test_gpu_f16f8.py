@@ -37,8 +37,12 @@ RAW = ["downs.0.0", "downs.0.1", "downs.1.0", "downs.1.1", "downs.2.0", "downs.2
        "ups.0.0", "ups.0.1", "ups.1.0", "ups.1.1"]
 
 
+both_convs = pytest.mark.parametrize("conv_ws", [False, True], ids=["conv_mfma", "conv_ws"])
+
+
+@both_convs
 @pytest.mark.parametrize("n_spks,B,T", [(1, 2, 64), (4, 3, 100)])
-def test_every_op_output_matches_oracle_taps(S, dev, n_spks, B, T):
+def test_every_op_output_matches_oracle_taps(S, dev, n_spks, B, T, conv_ws):
     """Every Block conv output (*.raw: both prologues, 64- and 128-channel tiles, the concatenated up-path inputs), tails,
     attention, resampling against the oracle's taps of the same call."""
     sd = O.make_estimator_state(seed=0, n_spks=n_spks)
@@ -46,8 +50,8 @@ def test_every_op_output_matches_oracle_taps(S, dev, n_spks, B, T):
     t = torch.linspace(0.15, 0.9, B)
     taps = {}
     ref = O.estimator_forward(sd, inp["z"], inp["mask"], inp["mu"], t, inp.get("spk"), taps=taps)
-    plan = S.Plan(n_spks=n_spks, keep_intermediates=True, precision=S.PREC_F16F8)
-    assert plan.conv_ws is False
+    plan = S.Plan(n_spks=n_spks, keep_intermediates=True, precision=S.PREC_F16F8, conv_ws=conv_ws)
+    assert plan.conv_ws is conv_ws
     blob = plan.pack(sd, dev)
     out = plan.estimator_forward(blob, inp["z"].to(dev), inp["mask"].to(dev), inp["mu"].to(dev), t.to(dev),
                                  inp["spk"].to(dev) if n_spks > 1 else None).cpu()
@@ -66,7 +70,8 @@ def test_every_op_output_matches_oracle_taps(S, dev, n_spks, B, T):
     assert relerr(out, ref) <= REL
 
 
-def test_local_block_conv_on_hip_inputs(S, dev):
+@both_convs
+def test_local_block_conv_on_hip_inputs(S, dev, conv_ws):
     """The 3x3 convolution alone: oracle conv2d applied to the HIP path's OWN input of the layer (so the error of the split is
     not mixed with its producers'), for a mask-prologue and a GroupNorm-prologue layer of every tile shape."""
     import torch.nn.functional as F
@@ -74,7 +79,7 @@ def test_local_block_conv_on_hip_inputs(S, dev):
     B, T = 2, 96
     inp = O.make_inputs(B, T, seed=5, ragged=True)
     t = torch.tensor([0.3, 0.8])
-    plan = S.Plan(keep_intermediates=True, precision=S.PREC_F16F8)
+    plan = S.Plan(keep_intermediates=True, precision=S.PREC_F16F8, conv_ws=conv_ws)
     blob = plan.pack(sd, dev)
     plan.estimator_forward(blob, inp["z"].to(dev), inp["mask"].to(dev), inp["mu"].to(dev), t.to(dev))
     torch.cuda.synchronize()
@@ -98,11 +103,12 @@ def test_local_block_conv_on_hip_inputs(S, dev):
     assert worst <= 6e-5
 
 
-def test_reverse_diffusion_n50_t1024_vs_oracle(S, dev):
+@both_convs
+def test_reverse_diffusion_n50_t1024_vs_oracle(S, dev, conv_ws):
     """The headline configuration's own N and T, one full and one ragged utterance (the scale-350 fixture: block inputs reach
     |x| = 450, tools/numerics_emul.py)."""
     sd = O.make_estimator_state(seed=0)
-    plan = S.Plan(precision=S.PREC_F16F8)
+    plan = S.Plan(precision=S.PREC_F16F8, conv_ws=conv_ws)
     blob = plan.pack(sd, dev)
     inp = O.make_inputs(2, 1024, seed=1234, ragged=True)
     ref = O.reverse_diffusion(sd, inp["z"], inp["mask"], inp["mu"], 50)
@@ -114,12 +120,13 @@ def test_reverse_diffusion_n50_t1024_vs_oracle(S, dev):
     assert err <= REL
 
 
-def test_reverse_diffusion_n50_t1024_mel_scale_abs(S, dev):
+@both_convs
+def test_reverse_diffusion_n50_t1024_mel_scale_abs(S, dev, conv_ws):
     """Same N and T on the mel-scale fixture: the north star's literal 1e-3 max-abs."""
     sd = dict(O.make_estimator_state(seed=0))
     sd["final_conv.weight"] = sd["final_conv.weight"] * 0.1
     sd["final_conv.bias"] = sd["final_conv.bias"] * 0.1
-    plan = S.Plan(precision=S.PREC_F16F8)
+    plan = S.Plan(precision=S.PREC_F16F8, conv_ws=conv_ws)
     blob = plan.pack(sd, dev)
     inp = O.make_inputs(1, 1024, seed=21, temperature=150.0, ragged=False)
     ref = O.reverse_diffusion(sd, inp["z"], inp["mask"], inp["mu"], 50)
@@ -130,11 +137,12 @@ def test_reverse_diffusion_n50_t1024_mel_scale_abs(S, dev):
     assert err <= 1e-3
 
 
-def test_batching_does_not_change_results(S, dev):
+@both_convs
+def test_batching_does_not_change_results(S, dev, conv_ws):
     """B = 16 == 8 + 8 and an utterance alone (half-height tiles) == the same utterance inside a batch, bit for bit; run to run
     reproducible; masked frames exactly zero."""
     sd = O.make_estimator_state(seed=0)
-    plan = S.Plan(precision=S.PREC_F16F8)
+    plan = S.Plan(precision=S.PREC_F16F8, conv_ws=conv_ws)
     blob = plan.pack(sd, dev)
     B, T = 16, 1024
     inp = O.make_inputs(B, T, seed=1234, ragged=True)
@@ -154,12 +162,13 @@ def test_batching_does_not_change_results(S, dev):
     assert relerr(a[3:4].cpu(), ref) <= REL
 
 
-def test_large_activations_degrade_gracefully(S, dev):
+@both_convs
+def test_large_activations_degrade_gracefully(S, dev, conv_ws):
     """Inputs 50x the fixture's scale drive Block inputs past the fp8 operands' range (|x| > 1024: q8(xl 2^S) saturates, |x| > 7168:
     q8(x 2^-D) as well) but not past the fp16 half's (65504): the result stays finite and fp16-grade (the hi*hi term is unaffected),
     never NaN -- v_cvt_pk_fp8_f32 returns NaN beyond 448, so both operands go through v_med3_f32 first (common.h)."""
     sd = O.make_estimator_state(seed=0)
-    plan = S.Plan(precision=S.PREC_F16F8)
+    plan = S.Plan(precision=S.PREC_F16F8, conv_ws=conv_ws)
     blob = plan.pack(sd, dev)
     inp = O.make_inputs(2, 64, seed=9)
     z, mu = inp["z"] * 50.0, inp["mu"] * 50.0
