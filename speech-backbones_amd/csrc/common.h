@@ -93,6 +93,22 @@ __device__ __forceinline__ float f8_sat(float v) { return __builtin_amdgcn_fmed3
 // two fp32 -> two fp8 e4m3 (RNE) in the low (hi_word = false) or high half of `old`
 template <bool HI>
 __device__ __forceinline__ int cvt2_fp8(float a, float b, int old) { return __builtin_amdgcn_cvt_pk_fp8_f32(a, b, old, HI); }
+// the same of a / scale, b / scale in one instruction (v_cvt_scalef32_pk_fp8_f32: probed, tools/probe/f8_probe.hip -- it DIVIDES by
+// the scale, rounds to nearest even like the plain conversion, and returns NaN beyond +-448 x scale as well)
+template <bool HI>
+__device__ __forceinline__ int cvt2_fp8_div(float a, float b, float scale, int old) {
+    return __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(__builtin_bit_cast(s16x2, old), a, b, scale, HI));
+}
+// the two cross-term operands of the f16 + fp8 split for a pair of values (x0, x1) with fp16 hi parts (h0, h1):
+// lo: q8((x - h) 2^S) saturated, xq: q8(x 2^-D) saturated, packed into the low or high half of a word
+template <bool HI>
+__device__ __forceinline__ void f8_cross_pair(float x0, float x1, _Float16 h0, _Float16 h1, int &lo, int &xq) {
+    constexpr float LS = 1.0f / (float)(1 << F8_S), LB = 448.0f * LS, XS = (float)(1 << F8_D), XB = 448.0f * XS;
+    const float t0 = __builtin_amdgcn_fmed3f(x0 - (float)h0, -LB, LB), t1 = __builtin_amdgcn_fmed3f(x1 - (float)h1, -LB, LB);
+    const float u0 = __builtin_amdgcn_fmed3f(x0, -XB, XB), u1 = __builtin_amdgcn_fmed3f(x1, -XB, XB);
+    lo = cvt2_fp8_div<HI>(t0, t1, LS, lo);
+    xq = cvt2_fp8_div<HI>(u0, u1, XS, xq);
+}
 
 // activation load / store through a buffer descriptor (per-lane byte offset + scalar byte offset), fp32 or bf16 storage
 template <typename AT>

@@ -491,10 +491,8 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
                     const _Float16 h0 = (_Float16)vv[i], h1 = (_Float16)vv[i + 1];
                     fh[i] = h0;
                     fh[i + 1] = h1;
-                    const float t0 = f8_sat((vv[i] - (float)h0) * (float)(1 << F8_S)), t1 = f8_sat((vv[i + 1] - (float)h1) * (float)(1 << F8_S));
-                    const float u0 = f8_sat(vv[i] * (1.0f / (float)(1 << F8_D))), u1 = f8_sat(vv[i + 1] * (1.0f / (float)(1 << F8_D)));
-                    if (i & 2) { lw[i >> 2] = cvt2_fp8<true>(t0, t1, lw[i >> 2]); xw[i >> 2] = cvt2_fp8<true>(u0, u1, xw[i >> 2]); }
-                    else { lw[i >> 2] = cvt2_fp8<false>(t0, t1, lw[i >> 2]); xw[i >> 2] = cvt2_fp8<false>(u0, u1, xw[i >> 2]); }
+                    if (i & 2) f8_cross_pair<true>(vv[i], vv[i + 1], h0, h1, lw[i >> 2], xw[i >> 2]);
+                    else f8_cross_pair<false>(vv[i], vv[i + 1], h0, h1, lw[i >> 2], xw[i >> 2]);
                 }
                 if (has) {
                     const int slot = pr * HC + lc;

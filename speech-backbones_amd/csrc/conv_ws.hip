@@ -35,7 +35,7 @@
 // Producer waves: [0] barrier wait, [1] staging (load wait + transform + LDS write), [2] re-request (+ tile setup), [3] finish_tile.
 // GTTS_WS_EXP (diagnostic builds only): timing ablations, results are WRONG.  1: the consumers never reload weights,
 // 2: the producers never re-request activations, 3: the producers skip transform + LDS write, 4: the consumers never re-read
-// B fragments, 5: no MFMAs
+// B fragments, 5: no MFMAs (f16 + fp8 form: 1, 4, 5 in the consumer loop; 2, 3 are common)
 #ifndef GTTS_DIAG
 #undef GTTS_WS_TRACE
 #undef GTTS_WS_EXP
@@ -267,35 +267,108 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
         int k = 0, cc = 0, slot = 0;
         if constexpr (F8) {
             // ---------------------------------------------------------------- f16 + fp8 consumer loop (32 channels per item)
-            // A tap is three passes over the MF x NF accumulators: fp16 k-step 0 (channels 0-15), fp16 k-step 1 (16-31), fp8 (both
-            // cross terms of all 32 channels) -- per accumulator always in this order, in every form of the kernel.  Registers: the
-            // weight fragments of the tap (wa, wb: fp16 k-steps; w8: fp8) are reloaded for the NEXT tap as soon as their last MFMA
-            // has issued (>= 20 MFMAs ahead of their next use); activation fragments are read from LDS one pass ahead.
-            f16x8 wa[MF], wb[MF], xa[NF], xb[NF];
-            i32x8 w8[MF];
-            constexpr int NH = (NF + 1) / 2 + (NF > 2 ? 0 : 0);      // fp8 B fragments are fetched in two groups: [0, NH) and [NH, NF)
-            u32x4 x8a[NH][2], x8b[NF - NH > 0 ? NF - NH : 1][2];
-            const int w_lane8 = (kg_l * 2 * MTP + m0 + l31) * 16;    // fp8 segments: g = kg_l * 2 + q
-            auto wload_h = [&](f16x8 &w, int mi, int kc, int chunk, int stage, int tap, int cot) {
+            // Wave mapping of this form: wave w owns output channels 32 w .. 32 w + 31 of the tile for ALL its rows (FR = 10, or 5 in the
+            // small form) -- the same FR accumulators per wave as the 64-channel x 5-row mapping of the bf16x3 form, but HALF the weight
+            // fragments per tap (16 registers: two fp16 k-steps + one fp8 operand), so the weights are double-buffered: the next tap's set
+            // is requested at the start of the tap, a whole tap (>= 1280 cycles) ahead of its first use.  Measured on the first version of
+            // this loop (64 x 5 mapping, 8 fragment loads per tap 640-1100 cycles ahead): 16.1k cycles per item for 11.5k of MFMA issue,
+            // 12.6k without weight reloads, 12.3k with the loads and NO MFMAs -- an L2 round trip under this load is ~1400 cycles
+            // (profiles/r05_ws_f16f8_ablations.txt).  Activation fragments are each used by one MFMA only now; they stream through a
+            // rolling window ~224 cycles ahead (sched_barrier pins the issue order; hipcc reuses the registers of dead fragments).
+            // A tap is three passes over the FR accumulators: fp16 k-step 0, fp16 k-step 1, fp8 (both cross terms) -- per accumulator always
+            // in this order, in both forms of the kernel.
+            constexpr int FR = TR;                                   // rows (accumulators) per wave
+            constexpr int NS = 3 * FR;                               // MFMA slots per tap
+            constexpr int LEAD = 224;                                // cycles between a fragment's ds_read and its MFMA
+            const int fm0 = wave * 32;
+            f32x16 facc[FR];
+            const int wl_h = (kg_l * MTP + fm0 + l31) * 16;         // lane's row in a (tap, kg) segment of the fp16 plane
+            const int wl_8 = (kg_l * 2 * MTP + fm0 + l31) * 16;     // ... of the fp8 plane: g = kg_l * 2 + q
+            struct WSet { f16x8 a, b; i32x8 w8; };
+            auto wload = [&](WSet &w, int chunk, int stage, int tap, int cot) {
                 const int blk = (chunk * 3 + stage) * ncotp + cot / cpp;
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
-                    rsw, w_lane + ((cot % cpp) * MT + mi * 32) * 16, blk * (WBLK16 * 16) + ((tap * NKG + kc * 2) * MTP) * 16, 0);
-                w = __builtin_bit_cast(f16x8, v);
+                const int cofs = (cot % cpp) * MT * 16;
+                const int so = blk * (WBLK16 * 16);
+                const u32x4 va = __builtin_amdgcn_raw_buffer_load_b128(rsw, wl_h + cofs, so + ((tap * NKG) * MTP) * 16, 0);
+                const u32x4 vb = __builtin_amdgcn_raw_buffer_load_b128(rsw, wl_h + cofs, so + ((tap * NKG + 2) * MTP) * 16, 0);
+                const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rsw, wl_8 + cofs, so + (((3 + tap) * NKG) * MTP) * 16, 0);
+                const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rsw, wl_8 + cofs, so + (((3 + tap) * NKG + 1) * MTP) * 16, 0);
+                w.a = __builtin_bit_cast(f16x8, va);
+                w.b = __builtin_bit_cast(f16x8, vb);
+                w.w8[0] = (int)q0[0]; w.w8[1] = (int)q0[1]; w.w8[2] = (int)q0[2]; w.w8[3] = (int)q0[3];
+                w.w8[4] = (int)q1[0]; w.w8[5] = (int)q1[1]; w.w8[6] = (int)q1[2]; w.w8[7] = (int)q1[3];
             };
-            auto wload_8 = [&](i32x8 &w, int mi, int chunk, int stage, int tap, int cot) {
-                const int blk = (chunk * 3 + stage) * ncotp + cot / cpp;
-                const int so = blk * (WBLK16 * 16) + (((3 + tap) * NKG) * MTP) * 16;
-                const int vo = w_lane8 + ((cot % cpp) * MT + mi * 32) * 16;
-                const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rsw, vo, so, 0);
-                const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rsw, vo, so + MTP * 16, 0);
-                w[0] = (int)q0[0]; w[1] = (int)q0[1]; w[2] = (int)q0[2]; w[3] = (int)q0[3];
-                w[4] = (int)q1[0]; w[5] = (int)q1[1]; w[6] = (int)q1[2]; w[7] = (int)q1[3];
-            };
-            auto mk8 = [](const u32x4 (&q)[2]) {
-                i32x8 r;
-                r[0] = (int)q[0][0]; r[1] = (int)q[0][1]; r[2] = (int)q[0][2]; r[3] = (int)q[0][3];
-                r[4] = (int)q[1][0]; r[5] = (int)q[1][1]; r[6] = (int)q[1][2]; r[7] = (int)q[1][3];
+            // start cycle of MFMA slot s of a tap (slots [0, FR): k-step 0, [FR, 2 FR): k-step 1, 32 cycles each; [2 FR, 3 FR): fp8, 64 each)
+            auto slot_t = [](int s2) constexpr { return s2 < 2 * FR ? 32 * s2 : 64 * FR + 64 * (s2 - 2 * FR); };
+            constexpr int TAPC = 128 * FR;                           // cycles per tap
+            // slot of THIS tap at whose start the fragment of slot u (u >= NS: slot u - NS of the next tap) is requested: the last slot
+            // starting at least LEAD cycles before u does; -1: before this tap began (requested at the item's start instead)
+            auto issue_slot = [&](int u) constexpr {
+                const int tu = u < NS ? slot_t(u) : TAPC + slot_t(u - NS);
+                int r = -1;
+                for (int q = 0; q < NS; ++q)
+                    if (slot_t(q) + LEAD <= tu) r = q;
                 return r;
+            };
+            WSet wc, wn_;
+            const int xl0 = kg_l * NPIX + l31;                       // lane's fragment column in a plane (rows start at the tile's row 0)
+            // tile epilogue of this mapping: bias, store, GroupNorm partial sums per 5-row band, written to s_red in the layout of the
+            // 64 x 5 mapping (wave row = band, fragment = this wave's channel block), so that finish_tile is common
+            auto f8_epilogue = [&](int par) {
+                const int oxx = tl.tx * 32 + l31;
+                const int out_bytes = a.cout * HW * AB;
+                const __amdgpu_buffer_rsrc_t rs_out =
+                    uniform_rsrc(reinterpret_cast<AT *>(a.out) + (size_t)tl.b * a.cout * HW, out_bytes);
+                const int ch0 = tl.cot * MT + fm0;
+                const bool col_ok = oxx < a.Wout;
+                const float *bias_l = s_epi + par * MT + fm0 + 4 * kg_l;
+#pragma unroll
+                for (int band = 0; band < FR / 5; ++band) {
+                    float st1[4], st2[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { st1[q] = 0.f; st2[q] = 0.f; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float bv[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) bv[i] = bias_l[8 * q + i];
+                        const int soff = (ch0 + 8 * q) * HW * AB;
+#pragma unroll
+                        for (int rr = 0; rr < 5; ++rr) {
+                            const int r = band * 5 + rr;
+                            const int oy = tl.ty * TR + r;
+                            if (oy >= a.Hout) continue;
+                            float v[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = fmaf(facc[r][4 * q + i], 1.0f / (float)(1 << F8_S), bv[i]);   // accumulators hold 2^S x the sum
+                            if (col_ok) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    st1[q] += v[i];
+                                    st2[q] = fmaf(v[i], v[i], st2[q]);
+                                }
+                                const int voff = (oy * a.Wout + oxx + 4 * kg_l * HW) * AB;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) st_act<AT>(v[i], rs_out, voff, soff + i * HW * AB);
+                            }
+                        }
+                    }
+                    float vals[8], tot[2];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { vals[q] = st1[q]; vals[4 + q] = st2[q]; }
+                    wave_sums_transposed<8>(vals, tot);
+                    if ((lane & 15) == 0) {
+                        const int rw = lane >> 4;
+                        // s_red slot of (wave row, fragment) in the 64 x 5 layout: wave row index = (channel half of the tile) * WN + band
+                        const int wold = NCW == 1 ? 0 : (wave >> 1) * WN + band, mi = NCW == 1 ? 0 : (wave & 1);
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk) {
+                            const int vi = kk + 2 * (rw & 1) + 4 * (rw >> 1);
+                            const int which = vi >> 2, q = vi & 3;
+                            s_red[par * (NCW * MF * 8) + ((wold * MF + mi) * 4 + q) * 2 + which] = tot[kk];
+                        }
+                    }
+                }
             };
             for (int i = 0; i < nitems; ++i) {
                 [[maybe_unused]] const unsigned long long tw0 = WT_NOW();
@@ -303,29 +376,33 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
                 [[maybe_unused]] const unsigned long long tw1 = WT_NOW();
                 WT_ADD(0, tw1, tw0);
                 const int par = k & 1;
-                const u32x4 *xh_p = s_img + slot * IMG16 + x_lane;                                  // fp16 plane, k-step 0 (k-step 1: + 2 NPIX)
-                const u32x4 *x8_p = s_img + slot * IMG16 + PLANE16 + x_lane + kg_l * NPIX;          // fp8 plane: g = 2 kg_l (second half: + NPIX)
+                const u32x4 *xh_p = s_img + slot * IMG16 + xl0;                                  // fp16 plane, k-step 0 (k-step 1: + 2 NPIX)
+                const u32x4 *x8_p = s_img + slot * IMG16 + PLANE16 + xl0 + kg_l * NPIX;          // fp8 plane: g = 2 kg_l (second half: + NPIX)
                 slot = slot + 1 == RING ? 0 : slot + 1;
                 if (cc == 0) {
                     // a tile starts cold: its first weight fragments are requested here (one exposed round trip per tile)
+                    wload(wn_, 0, 0, 0, tl.cot);
 #pragma unroll
-                    for (int mi = 0; mi < MF; ++mi) {
-                        wload_h(wa[mi], mi, 0, 0, 0, 0, tl.cot);
-                        wload_h(wb[mi], mi, 1, 0, 0, 0, tl.cot);
-                        wload_8(w8[mi], mi, 0, 0, 0, tl.cot);
-                    }
+                    for (int r = 0; r < FR; ++r)
 #pragma unroll
-                    for (int mi = 0; mi < MF; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < NF; ++ni)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+                        for (int e = 0; e < 16; ++e) facc[r][e] = 0.f;
                     for (int c = tid; c < MT; c += NCT) s_epi[par * MT + c] = a.bias[tl.cot * MT + c];
                 }
-#pragma unroll
-                for (int ni = 0; ni < NF; ++ni) xa[ni] = *reinterpret_cast<const f16x8 *>(xh_p + ni * HC);
                 const bool last_c = cc + 1 == nchunk;
                 const int ncn = last_c ? cc : cc + 1;               // (the last chunk re-requests its own first tap: never used)
+                // activation fragments of the tap in flight: one variable per slot (dead ones are reused by the register allocator)
+                f16x8 fa[FR], fb[FR];
+                u32x4 f8l[FR], f8h[FR];
+                auto fetch = [&](int u, int st, int j) {             // fragment of slot u (< NS) of tap (st, j)
+                    const int r = u % FR, off = (r + st) * HC + j;
+                    if (u < FR) fa[r] = *reinterpret_cast<const f16x8 *>(xh_p + off);
+                    else if (u < 2 * FR) fb[r] = *reinterpret_cast<const f16x8 *>(xh_p + 2 * NPIX + off);
+                    else { f8l[r] = x8_p[off]; f8h[r] = x8_p[NPIX + off]; }
+                };
+                // fragments of tap (0, 0) whose request slot lies before the tap
+#pragma unroll
+                for (int u = 0; u < NS; ++u)
+                    if (issue_slot(u) < 0) fetch(u, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int st = 0; st < 3; ++st) {
@@ -333,79 +410,49 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
                     for (int j = 0; j < 3; ++j) {
                         const bool last_t = st == 2 && j == 2;
                         const int nst = j == 2 ? st + 1 : st, nj = j == 2 ? 0 : j + 1;      // next tap inside the chunk
-                        const int nch = last_t ? ncn : cc, ns = last_t ? 0 : nst, nt = last_t ? 0 : nj;
-                        // ---- pass A: fp16 k-step 0; fetch k-step 1's activation fragments
-#pragma unroll
-                        for (int ni = 0; ni < NF; ++ni) xb[ni] = *reinterpret_cast<const f16x8 *>(xh_p + 2 * NPIX + (ni + st) * HC + j);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int mi = 0; mi < MF; ++mi) {
-#pragma unroll
-                            for (int ni = 0; ni < NF; ++ni)
-                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[mi], xa[ni], acc[mi][ni], 0, 0, 0);
-                            __builtin_amdgcn_sched_barrier(0);
-                            wload_h(wa[mi], mi, 0, nch, ns, nt, tl.cot);          // dead: request the next tap's
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                        // ---- pass B: fp16 k-step 1; fetch the first group of fp8 fragments
-#pragma unroll
-                        for (int ni = 0; ni < NH; ++ni) {
-                            x8a[ni][0] = x8_p[(ni + st) * HC + j];
-                            x8a[ni][1] = x8_p[NPIX + (ni + st) * HC + j];
+                        wc = wn_;                                    // (a rename in the unrolled code; one copy on the loop's back edge)
+                        // next tap's weights, a whole tap ahead
+                        if (GTTS_WS_EXP != 1) {
+                            if (last_t) wload(wn_, ncn, 0, 0, tl.cot); else wload(wn_, cc, nst, nj, tl.cot);
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int mi = 0; mi < MF; ++mi) {
+                        for (int s2 = 0; s2 < NS; ++s2) {
+                            // requests due at this slot: later slots of this tap, then the first slots of the next tap (same image)
 #pragma unroll
-                            for (int ni = 0; ni < NF; ++ni)
-                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[mi], xb[ni], acc[mi][ni], 0, 0, 0);
-                            __builtin_amdgcn_sched_barrier(0);
-                            wload_h(wb[mi], mi, 1, nch, ns, nt, tl.cot);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                        // ---- pass C1: fp8 on the first group; fetch the second group
-                        if constexpr (NF > NH) {
-#pragma unroll
-                            for (int ni = NH; ni < NF; ++ni) {
-                                x8b[ni - NH][0] = x8_p[(ni + st) * HC + j];
-                                x8b[ni - NH][1] = x8_p[NPIX + (ni + st) * HC + j];
+                            for (int u = s2 + 1; u < 2 * NS; ++u) {
+                                if (issue_slot(u) != s2) continue;
+                                if (u < NS) fetch(u, st, j);
+                                else if (!last_t && issue_slot(u - NS) < 0) fetch(u - NS, nst, nj);     // (the others are requested inside their own tap)
                             }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int ni = 0; ni < NH; ++ni) {
-                            const i32x8 b8 = mk8(x8a[ni]);
-#pragma unroll
-                            for (int mi = 0; mi < MF; ++mi)
-                                acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8[mi], b8, acc[mi][ni], 0, 0, 0, 0, 0, 0);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        // ---- pass C2: fp8 on the second group; fetch the next tap's k-step 0 fragments (same image)
-                        if (!last_t) {
-#pragma unroll
-                            for (int ni = 0; ni < NF; ++ni) xa[ni] = *reinterpret_cast<const f16x8 *>(xh_p + (ni + nst) * HC + nj);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (NF > NH) {
-#pragma unroll
-                            for (int ni = NH; ni < NF; ++ni) {
-                                const i32x8 b8 = mk8(x8b[ni - NH]);
-#pragma unroll
-                                for (int mi = 0; mi < MF; ++mi)
-                                    acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8[mi], b8, acc[mi][ni], 0, 0, 0, 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            const int r = s2 % FR;
+#if GTTS_WS_EXP == 5 && defined(__HIP_DEVICE_COMPILE__)
+                            // (diagnostic builds, device pass only: on the host pass an asm with a "v" operand silently drops the kernel's stub)
+                            if (s2 < FR) asm volatile("" ::"v"(wc.a), "v"(fa[r]));
+                            else if (s2 < 2 * FR) asm volatile("" ::"v"(wc.b), "v"(fb[r]));
+                            else asm volatile("" ::"v"(wc.w8), "v"(f8l[r]), "v"(f8h[r]));
+                            if (false)
+#endif
+                            if (s2 < FR) {
+                                facc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc.a, fa[r], facc[r], 0, 0, 0);
+                            } else if (s2 < 2 * FR) {
+                                facc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc.b, fb[r], facc[r], 0, 0, 0);
+                            } else {
+                                i32x8 b8;
+                                b8[0] = (int)f8l[r][0]; b8[1] = (int)f8l[r][1]; b8[2] = (int)f8l[r][2]; b8[3] = (int)f8l[r][3];
+                                b8[4] = (int)f8h[r][0]; b8[5] = (int)f8h[r][1]; b8[6] = (int)f8h[r][2]; b8[7] = (int)f8h[r][3];
+                                facc[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wc.w8, b8, facc[r], 0, 0, 0, 0, 0, 0);
                             }
+                            __builtin_amdgcn_sched_barrier(0);
                         }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int mi = 0; mi < MF; ++mi) wload_8(w8[mi], mi, nch, ns, nt, tl.cot);
-                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 [[maybe_unused]] const unsigned long long tw2 = WT_NOW();
                 WT_ADD(1, tw2, tw1);
                 WT_ADD(3, 1ull, 0ull);
                 if (!last_c) { ++cc; continue; }
-                ws_epilogue(par);
+                f8_epilogue(par);
                 cc = 0;
                 ++k;
                 tl = decode(k);
@@ -635,7 +682,7 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
                 bf16x8 vh[4], vl[4];
                 [[maybe_unused]] f16x8 fh[4];                   // f16 + fp8 split: fp16 hi values of the four frames ...
                 [[maybe_unused]] int lw[4][2], xw[4][2];        // ... and their fp8 operands q8(xl 2^S), q8(x 2^-D): 8 channels = 8 bytes per frame
-                [[maybe_unused]] float tprev[4], uprev[4];
+                [[maybe_unused]] float vprev[4];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     if (GTTS_WS_EXP != 3) {
@@ -659,13 +706,11 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
                             if constexpr (F8) {
                                 const _Float16 h = (_Float16)v;
                                 fh[j][i] = h;
-                                const float t = f8_sat((v - (float)h) * (float)(1 << F8_S)), u = f8_sat(v * (1.0f / (float)(1 << F8_D)));
                                 if (i & 1) {        // channels (i - 1, i) of frame j -> two fp8 bytes of word i >> 2, half (i >> 1) & 1
-                                    if (i & 2) { lw[j][i >> 2] = cvt2_fp8<true>(tprev[j], t, lw[j][i >> 2]); xw[j][i >> 2] = cvt2_fp8<true>(uprev[j], u, xw[j][i >> 2]); }
-                                    else { lw[j][i >> 2] = cvt2_fp8<false>(tprev[j], t, 0); xw[j][i >> 2] = cvt2_fp8<false>(uprev[j], u, 0); }
+                                    if (i & 2) f8_cross_pair<true>(vprev[j], v, fh[j][i - 1], h, lw[j][i >> 2], xw[j][i >> 2]);
+                                    else { lw[j][i >> 2] = 0; xw[j][i >> 2] = 0; f8_cross_pair<false>(vprev[j], v, fh[j][i - 1], h, lw[j][i >> 2], xw[j][i >> 2]); }
                                 } else {
-                                    tprev[j] = t;
-                                    uprev[j] = u;
+                                    vprev[j] = v;
                                 }
                             } else if constexpr (NSPLIT > 1) {
                                 __bf16 h, l;
@@ -830,17 +875,32 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
                 finish_tile(decode(kt), kt & 1);
             }
         };
+        // f16 + fp8 split: ONE register set -- an item is 32 channels (two of them cover what the bf16x3 form keeps in flight with
+        // two sets), and a second 64-register set spills the transform
+        constexpr bool ONE_SET = F8;
         load_all(rawA);
 #pragma unroll
         for (int it = 0; it < LITER; ++it)
 #pragma unroll
             for (int j = 0; j < 4; ++j) m_cur[it][j] = m_nxt[it][j];
-        load_all(rawB);
+        if constexpr (!ONE_SET) load_all(rawB);
         lds_barrier();                                 // (P) s_par of tile 0 visible to every producer wave
         // D items ahead (host guarantees nchunk >= 2: the first two items share a tile, so s_par[0] is all they need);
         // the register sets alternate A, B, A, ... from here on
         step(rawA);
         if (D > 1) step(rawB);
+        if constexpr (ONE_SET) {
+            static_assert(!ONE_SET || D == 1, "one register set: one item ahead");
+            for (int i = 0; i < nitems; ++i) {
+                [[maybe_unused]] const unsigned long long tb0 = WT_NOW();
+                lds_barrier();
+                [[maybe_unused]] const unsigned long long tb1 = WT_NOW();
+                WT_ADD(0, tb1, tb0);
+                fin(i);
+                WT_ADD(3, WT_NOW(), tb1);
+                step(rawA);
+            }
+        } else
         for (int i = 0; i < nitems; i += 2) {
             [[maybe_unused]] unsigned long long tb0 = WT_NOW();
             lds_barrier();

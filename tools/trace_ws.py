@@ -9,7 +9,9 @@ from oracle import gradtts_oracle as O  # noqa: E402  (weights only; diagnostic)
 B, T = 16, 1024
 dev = torch.device("cuda:0")
 sd = O.make_estimator_state(seed=0)
-plan = S.Plan(n_spks=1, streams=0)
+prec = {"bf16x3": S.PREC_BF16X3, "f16f8": S.PREC_F16F8}[os.environ.get("TRACE_PREC", "bf16x3")]
+plan = S.Plan(n_spks=1, streams=0, conv_ws=True, precision=prec)
+print("precision", os.environ.get("TRACE_PREC", "bf16x3"), "conv_ws", plan.conv_ws)
 packed = plan.pack(sd, dev)
 g = torch.Generator().manual_seed(0)
 x = torch.randn(B, 80, T, generator=g).to(dev)
