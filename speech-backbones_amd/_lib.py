@@ -261,11 +261,16 @@ class Plan:
         third of the call is bandwidth-bound kernels that three sub-batch streams hide under the convolutions of another
         sub-batch (measured on one box: 7.05 ms per U-Net call against 7.47 with the persistent kernel on two streams).
 
+        precision PREC_F16F8 (the drop-in modules' default): the 128-channel-and-wider Block convolutions run the f16 + fp8 split on
+        the persistent kernel (conv_ws defaults to True), unsplit -- measured on one box, ms per U-Net call at B = 16: 6.68 against
+        7.16 for bf16x3 on three streams; with the persistent kernel two sub-batch streams are slower (6.80 vs 6.64), and sub-batch
+        streams confined to disjoint halves of the CUs (hipExtStreamCreateWithCUMask) slower still (7.07; bf16x3: 7.70 vs 7.16).
+
         streams: number of sub-batches gtts_reverse_diffusion runs side by side on torch side streams owned by this
         object and registered with gtts_plan_set_streams (0 / 1: no split; $GTTS_STREAMS overrides the default).  Default 3;
-        2 with conv_ws (8 + 8 utterances fill the chip in whole rounds of persistent workgroups)."""
+        2 with conv_ws in bf16x3 (8 + 8 utterances fill the chip in whole rounds of persistent workgroups); 0 with PREC_F16F8."""
         if conv_ws is None:
-            conv_ws = int(dim) >= 128
+            conv_ws = int(dim) >= 128 or int(precision) == PREC_F16F8
         conv_ws = bool(conv_ws) and int(precision) in (PREC_BF16X3, PREC_F16F8)
         self._kw = dict(dim=dim, n_feats=n_feats, n_spks=n_spks, spk_emb_dim=spk_emb_dim, groups=groups,
                         pe_scale=pe_scale, beta_min=beta_min, beta_max=beta_max, precision=precision,
@@ -280,7 +285,7 @@ class Plan:
         _check(lib().gtts_plan_create(ctypes.byref(self.cfg), ctypes.byref(self._h)), "gtts_plan_create")
         self._ws = {}
         if streams is None:
-            streams = int(os.environ.get("GTTS_STREAMS", "2" if conv_ws else "3"))
+            streams = int(os.environ.get("GTTS_STREAMS", ("0" if int(precision) == PREC_F16F8 else "2") if conv_ws else "3"))
         self._nstreams = 0 if int(streams) < 2 else min(int(streams), 4)
         self._side = None           # (device, [torch.cuda.Stream])
         self._graph = False

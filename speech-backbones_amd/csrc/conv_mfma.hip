@@ -1017,16 +1017,21 @@ static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
     return hipGetLastError();
 }
 
-// See common.h.  The LDS bound keeps two workgroups per CU: one 32-channel activation image (fp16 plane + fp8 plane), one weight
-// stage of three taps, the prologue's per-channel parameters.
+// See common.h.  LDS of the uniform-wave form: one 32-channel activation image (fp16 plane + fp8 plane), one weight stage of three
+// taps, the prologue's per-channel parameters.
 bool conv_f16f8_ok(int mode, int c0, int c1, int cout, int pro, int epi) {
     const int cin = c0 + c1;
     if (mode != CONV_C3 || epi != EPI_STATS || (pro != PRO_MASK && pro != PRO_GN)) return false;
-    if (cin % 32 != 0 || (c1 != 0 && c0 % 32 != 0) || cout % 64 != 0) return false;
+    // 128-channel cout tiles only.  The 64-channel tile was built and measured (round 5, same box, us per launch at B = 16):
+    // 219.6 / 209.9 (mask / GroupNorm prologue) against 214.2 / 186.5 in bf16x3 -- two workgroups per CU (68 KB of LDS at 32-channel
+    // chunks) instead of three, twice the staging per MFMA, and LDS fragment traffic that no longer hides behind the shorter MFMA
+    // phase; 6.68 vs 6.83 ms per U-Net call with those layers left on bf16x3.
+    if (cin % 32 != 0 || (c1 != 0 && c0 % 32 != 0) || cout % 128 != 0) return false;
     const ConvGeom g = conv_geom(mode, cin, cout, 1);
     if (cout % g.MT != 0) return false;
     const int npix = (g.TR + 2) * 34, nkg = 2 * g.kch;
-    return conv_smem_bytes(npix, nkg, g.tps * g.MT * 2 * nkg, cin, pro, g.MT) <= (size_t)80 * 1024;
+    // (two workgroups per CU up to 256 input channels with the GroupNorm prologue; wider layers -- DiffVC -- still fit one)
+    return conv_smem_bytes(npix, nkg, g.tps * g.MT * 2 * nkg, cin, pro, g.MT) <= (size_t)160 * 1024;
 }
 
 // Small launches (B = 1, what Grad-TTS/inference.py runs): a 3x3 layer whose regular tiling yields fewer than GTTS_SMALL_WGS
@@ -1059,11 +1064,12 @@ static hipError_t launch_prec(const ConvArgs &a, hipStream_t st) {
         // GTTS_PREC_F16F8: the layer's weights are packed in the f16 + fp8 format exactly when conv_f16f8_ok says so (plan.hip)
         if (a.f16f8 && conv_f16f8_ok(MODE, a.c0, a.c1, a.cout, PRO, EPI)) {
             if (a.act_bf16 || a.nsplit != 2) return hipErrorInvalidValue;
-            if (conv_small_tiles(MODE, a.cout, a.Hout, a.Wout, a.B)) {      // half-height tiles, as below
-                if constexpr (WM == 2) return launch_cfg<MODE, 4, 1, 1, 2, PRO, EPI, 3, 1, float, 2, 0>(a, st);
-                else return launch_cfg<MODE, 2, 2, 1, 2, PRO, EPI, 3, 1, float, 2, 0>(a, st);
+            if constexpr (WM == 2) {      // (conv_f16f8_ok: 128-channel cout tiles only)
+                if (conv_small_tiles(MODE, a.cout, a.Hout, a.Wout, a.B))      // half-height tiles, as below
+                    return launch_cfg<MODE, 4, 1, 1, 2, PRO, EPI, 3, 1, float, 2, 0>(a, st);
+                return launch_cfg<MODE, WM, WN, MF, 2, PRO, EPI, 3, 1, float, 2, 0>(a, st);
             }
-            return launch_cfg<MODE, WM, WN, MF, 2, PRO, EPI, 3, 1, float, 2, 0>(a, st);
+            return hipErrorInvalidValue;
         }
     }
     if constexpr (MODE == CONV_C3 && PRO != PRO_IGLU) {

@@ -40,10 +40,18 @@ def _view(ws, info, name):
     return ws[off: off + 4 * n].view(torch.float32).view(*dims).cpu()
 
 
-def test_vc_estimator_golden_and_condition_path(S, dev):
+both_precs = pytest.mark.parametrize("prec", ["bf16x3", "f16f8"])
+
+
+def _prec(S, prec):
+    return {"bf16x3": S.PREC_BF16X3, "f16f8": S.PREC_F16F8}[prec]
+
+
+@both_precs
+def test_vc_estimator_golden_and_condition_path(S, dev, prec):
     g = golden("vc_dim64.npz")
     sd = V.make_state(dim_base=64, dim_cond=128, use_ref_t=True, seed=int(g["seed"]))
-    plan = S.Plan(dim=64, arch=1, keep_intermediates=True)
+    plan = S.Plan(dim=64, arch=1, keep_intermediates=True, precision=_prec(S, prec))
     blob = plan.pack(sd, dev)
     args = [_t(g[k]).to(dev) for k in ("z", "mask", "mean", "xt_ref", "ref_mask", "c", "t")]
     out = plan.vc_estimator_forward(blob, *args).cpu()
@@ -62,10 +70,11 @@ def test_vc_estimator_golden_and_condition_path(S, dev):
 
 
 @pytest.mark.parametrize("mode", ["pf", "em", "ml"])
-def test_vc_sampler_modes_match_reference_golden(S, dev, mode):
+@both_precs
+def test_vc_sampler_modes_match_reference_golden(S, dev, mode, prec):
     g = golden("vc_dim64.npz")
     sd = V.make_state(dim_base=64, dim_cond=128, use_ref_t=True, seed=int(g["seed"]))
-    plan = S.Plan(dim=64, arch=1)
+    plan = S.Plan(dim=64, arch=1, precision=_prec(S, prec))
     blob = plan.pack(sd, dev)
     a = {k: _t(g[k]).to(dev) for k in ("z", "mask", "mean", "ref", "ref_mask", "mean_ref", "c", "noise")}
     out = plan.vc_reverse_diffusion(blob, a["z"], a["mask"], a["mean"], a["ref"], a["ref_mask"], a["mean_ref"], a["c"], 3, mode,
@@ -85,10 +94,11 @@ def test_vc_without_ref_block(S, dev):
     assert relerr(out, ref) <= REL
 
 
-def test_vc_full_width_small_shape(S, dev):
+@both_precs
+def test_vc_full_width_small_shape(S, dev, prec):
     """dim_unet = 256 (the published DiffVC decoder: 117.8 M parameters, channels 256/512/1024)."""
     sd = V.make_state(dim_base=256, seed=1)
-    plan = S.Plan(dim=256, arch=1)
+    plan = S.Plan(dim=256, arch=1, precision=_prec(S, prec))
     blob = plan.pack(sd, dev)
     inp = V.make_inputs(2, 16, 20, seed=3)
     t = torch.tensor([0.6, 1.0])
@@ -155,11 +165,12 @@ def _oracle_step(sd, xt, inp, N, mode, i, eps):
     return (xt - dxt) * inp["mask"]
 
 
-def test_vc_ml_config4_n6_free_running_dim256(S, dev):
+@both_precs
+def test_vc_ml_config4_n6_free_running_dim256(S, dev, prec):
     """BASELINE config 4 at its own N: the published decoder width (dim 256), fast maximum-likelihood sampler, N = 6, all six
     steps free-running against the oracle (kappa / omega / sigma depend on N; the step times are computed on the device)."""
     sd = V.make_state(dim_base=256, seed=6)
-    plan = S.Plan(dim=256, arch=1)
+    plan = S.Plan(dim=256, arch=1, precision=_prec(S, prec))
     blob = plan.pack(sd, dev)
     inp = V.make_inputs(1, 64, 32, seed=12)
     g = torch.Generator().manual_seed(77)
@@ -213,11 +224,12 @@ def test_vc_ml_n30_free_running_dim64(S, dev):
     assert e <= 2 * REL
 
 
-def test_vc_ml_n30_free_running_dim256(S, dev):
+@both_precs
+def test_vc_ml_n30_free_running_dim256(S, dev, prec):
     """The published decoder width at the notebook's own N, all 30 steps free-running (round 3 had this teacher-forced only):
     T = 128 keeps the 117.8 M-parameter CPU oracle to well under a minute."""
     sd = V.make_state(dim_base=256, seed=6)
-    plan = S.Plan(dim=256, arch=1)
+    plan = S.Plan(dim=256, arch=1, precision=_prec(S, prec))
     blob = plan.pack(sd, dev)
     inp = V.make_inputs(1, 128, 40, seed=31)
     g = torch.Generator().manual_seed(19)
