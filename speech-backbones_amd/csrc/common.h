@@ -286,7 +286,9 @@ hipError_t launch_conv_up4(const ConvArgs &a, hipStream_t st);
 // Block convolutions that take the f16 + fp8 split when the plan's precision is GTTS_PREC_F16F8 (conv_mfma.hip): 3x3, whole
 // 32-channel chunks (a concatenated input splitting on one), mask / GroupNorm prologue, statistics epilogue, and an LDS
 // footprint that leaves two workgroups per CU.  Decides the packing of the layer's weights as well (pack.hip).
-bool conv_f16f8_ok(int mode, int c0, int c1, int cout, int pro, int epi);
+// use_ws: the plan runs eligible layers on the persistent kernel (gtts_unet_cfg.conv_ws) -- 64-channel layers take the split only there.
+bool conv_f16f8_ok(int mode, int c0, int c1, int cout, int pro, int epi, int use_ws);
+bool conv_ws_f8_fits(int cin, int pro, int mt);
 bool conv_small_tiles(int mode, int cout, int Hout, int Wout, int B);   // half-height tiles for launches smaller than the chip
 bool conv_rowpair_stats(int mode, int cout, int Hout, int Wout);        // GroupNorm partial slots per row pair (batch-size independent)
 

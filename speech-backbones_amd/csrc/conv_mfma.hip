@@ -45,6 +45,10 @@
 #ifndef GTTS_F8_WAVES
 #define GTTS_F8_WAVES 2
 #endif
+// 0 (A/B builds): 64-channel layers stay bf16x3 in GTTS_PREC_F16F8 plans
+#ifndef GTTS_F8_WS64
+#define GTTS_F8_WS64 1
+#endif
 #define GTTS_WAVES(MODE) ((MODE) == CONV_DN ? GTTS_DN_WAVES : GTTS_C3_WAVES)
 #define GTTS_WAVES_NS(MODE, NSPLIT) ((MODE) == CONV_DN ? GTTS_DN_WAVES : ((NSPLIT) == 3 ? GTTS_F8_WAVES : ((NSPLIT) == 1 ? GTTS_C3_WAVES_BF16 : GTTS_C3_WAVES)))
 // Diagnostics exist only in -DGTTS_DIAG builds (tools/abexp.sh, tools/trace_conv.py); the product library is compiled
@@ -1019,16 +1023,17 @@ static hipError_t launch_cfg(const ConvArgs &a_in, hipStream_t st) {
 
 // See common.h.  LDS of the uniform-wave form: one 32-channel activation image (fp16 plane + fp8 plane), one weight stage of three
 // taps, the prologue's per-channel parameters.
-bool conv_f16f8_ok(int mode, int c0, int c1, int cout, int pro, int epi) {
+bool conv_f16f8_ok(int mode, int c0, int c1, int cout, int pro, int epi, int use_ws) {
     const int cin = c0 + c1;
     if (mode != CONV_C3 || epi != EPI_STATS || (pro != PRO_MASK && pro != PRO_GN)) return false;
-    // 128-channel cout tiles only.  The 64-channel tile was built and measured (round 5, same box, us per launch at B = 16):
-    // 219.6 / 209.9 (mask / GroupNorm prologue) against 214.2 / 186.5 in bf16x3 -- two workgroups per CU (68 KB of LDS at 32-channel
-    // chunks) instead of three, twice the staging per MFMA, and LDS fragment traffic that no longer hides behind the shorter MFMA
-    // phase; 6.68 vs 6.83 ms per U-Net call with those layers left on bf16x3.
-    if (cin % 32 != 0 || (c1 != 0 && c0 % 32 != 0) || cout % 128 != 0) return false;
+    if (cin % 32 != 0 || (c1 != 0 && c0 % 32 != 0)) return false;
+    // 64-channel layers: only on the persistent kernel (conv_ws.hip: four consumer + eight producer waves).  The uniform-wave 64-channel
+    // tile was built and measured (round 5, same box, us per launch at B = 16): 219.6 / 209.9 (mask / GroupNorm prologue) against
+    // 214.2 / 186.5 in bf16x3 -- two workgroups per CU (68 KB of LDS at 32-channel chunks) instead of three, twice the staging per MFMA,
+    // and LDS fragment traffic that no longer hides behind the shorter MFMA phase; those instances are gone.
+    if (cout == 64) return GTTS_WS && GTTS_F8_WS64 && use_ws && cin >= 64 && conv_ws_f8_fits(cin, pro, 64);
+    if (cout % 128 != 0) return false;
     const ConvGeom g = conv_geom(mode, cin, cout, 1);
-    if (cout % g.MT != 0) return false;
     const int npix = (g.TR + 2) * 34, nkg = 2 * g.kch;
     // (two workgroups per CU up to 256 input channels with the GroupNorm prologue; wider layers -- DiffVC -- still fit one)
     return conv_smem_bytes(npix, nkg, g.tps * g.MT * 2 * nkg, cin, pro, g.MT) <= (size_t)160 * 1024;
@@ -1062,7 +1067,7 @@ static hipError_t launch_prec(const ConvArgs &a, hipStream_t st) {
     const bool fullc = a.cin % 16 == 0 && (a.c1 == 0 || a.c0 % 16 == 0);
     if constexpr (MODE == CONV_C3 && EPI == EPI_STATS && (PRO == PRO_MASK || PRO == PRO_GN)) {
         // GTTS_PREC_F16F8: the layer's weights are packed in the f16 + fp8 format exactly when conv_f16f8_ok says so (plan.hip)
-        if (a.f16f8 && conv_f16f8_ok(MODE, a.c0, a.c1, a.cout, PRO, EPI)) {
+        if (a.f16f8 && conv_f16f8_ok(MODE, a.c0, a.c1, a.cout, PRO, EPI, a.use_ws)) {
             if (a.act_bf16 || a.nsplit != 2) return hipErrorInvalidValue;
             if constexpr (WM == 2) {      // (conv_f16f8_ok: 128-channel cout tiles only)
                 if (conv_small_tiles(MODE, a.cout, a.Hout, a.Wout, a.B))      // half-height tiles, as below

@@ -50,9 +50,9 @@
 #define GTTS_TRACE_CIN 128
 #endif
 #if GTTS_WS_TRACE
-__device__ unsigned long long g_ws_trace[64 * 8 * 8];
+__device__ unsigned long long g_ws_trace[64 * 16 * 8];      // [workgroup][wave (up to 12)][slot]
 extern "C" int gtts_debug_trace_ws(unsigned long long *dst, int n) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ws_trace), sizeof(unsigned long long) * (n < 4096 ? n : 4096));
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ws_trace), sizeof(unsigned long long) * (n < 8192 ? n : 8192));
 }
 #define WT_NOW() (tr_on ? __builtin_amdgcn_s_memtime() : 0ull)
 #define WT_ADD(slot, t1, t0) do { if (tr_on) tr_sum[slot] += (t1) - (t0); } while (0)
@@ -67,18 +67,27 @@ extern "C" int gtts_debug_trace_ws(unsigned long long *dst, int n) {
 
 namespace gtts {
 
+// producer waves of the f16 + fp8 64-channel tile: 8 (three waves per SIMD, 168 registers: the consumers' fragment window shrinks to
+// 96 cycles) or 4 (256 registers, 224-cycle window; the producers then bound the tile)
+#ifndef GTTS_WS64_NPW
+#define GTTS_WS64_NPW 8
+#endif
 template <int WM, int WN, int MF, int NF, int NKGT = 2>
 struct WsCfg {
-    static constexpr int NCW = WM * WN;          // consumer waves: 4, or 1 in the small-launch form
-    static constexpr int NPW = NCW == 1 ? 2 : NCW;   // producer waves (small form: a 32-channel consumer tile takes 4.3k cycles per
-                                                     // chunk, one producer wave needs 6k to stage it)
-    static constexpr int NT = (NCW + NPW) * 64;  // threads per workgroup
+    static constexpr int NCW = WM * WN;          // consumer wave ROWS x COLUMNS of the statistics layout: 4, 2 (64-channel tile) or 1
+    // waves that actually run: the f16 + fp8 form (NKGT == 4) maps one wave to a 32-channel block (x a 5-row band for the 64-channel
+    // tile), so the 64-channel tile still has four consumers; it takes eight producer waves (twice the staging per MFMA)
+    static constexpr int NCWP = (NKGT == 4 && WM == 1 && WN == 2) ? 4 : NCW;
+    static constexpr int NPW = NCW == 1 ? 2 : ((NKGT == 4 && WM == 1 && WN == 2) ? GTTS_WS64_NPW : NCW);   // producer waves (small form: a 32-channel
+                                                     // consumer tile takes 4.3k cycles per chunk, one producer wave needs 6k to stage it)
+    static constexpr int NT = (NCWP + NPW) * 64; // threads per workgroup
     static constexpr int MT = WM * MF * 32;      // output channels per workgroup
     static constexpr int TR = WN * NF;           // output rows per workgroup
     static constexpr int HR = TR + 2, HC = 34;   // halo tile
     static constexpr int NPIX = HR * HC;
     static constexpr int NKG = NKGT;             // 8-channel groups per chunk: 2 (16 channels), or 4 (32) for the f16 + fp8 split
-    static_assert((NCW == 4 && MF == 2) || (NCW == 1 && MF == 1), "four consumer waves of 64 channels, or one of 32");
+    static_assert((NCW == 4 && MF == 2) || (NCW == 1 && MF == 1) || (NKGT == 4 && NCW == 2 && MF == 2 && WM == 1),
+                  "four consumer waves of 64 channels, one of 32, or (f16 + fp8) the 64-channel tile");
 };
 
 // nsplit planes (1: hi; 2: hi + lo, or fp16 hi + fp8 cross-term operands) of nkg 8-channel groups per ring slot
@@ -92,14 +101,16 @@ static inline size_t ws_smem_bytes(int npix, int nsplit, int ring, int cin, int 
 // [kg 0..3][pixel][8 channels], plane 1 the fp8 cross-term operands [g = plane * 2 + half][pixel][16 channels]; the consumers issue
 // two fp16 k-steps and one fp8 K = 64 step per tap (2/3 of the bf16x3 MFMA cycles, 1.53x its sustained rate).
 template <int WM, int WN, int MF, int NF, int PRO, int NSPLIT, typename AT, int RING>
-__global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_kernel(const ConvArgs a) {
+__global__ __launch_bounds__((WsCfg<WM, WN, MF, NF, NSPLIT == 3 ? 4 : 2>::NT), ((WsCfg<WM, WN, MF, NF, NSPLIT == 3 ? 4 : 2>::NT) >= 768 ? 3 : 2))
+void conv3x3_ws_kernel(const ConvArgs a) {
     constexpr bool F8 = NSPLIT == 3;
     using C = WsCfg<WM, WN, MF, NF, F8 ? 4 : 2>;
     constexpr int AB = (int)sizeof(AT);
     constexpr int MT = C::MT, TR = C::TR, HC = C::HC, NPIX = C::NPIX, NKG = C::NKG, NCW = C::NCW;
     constexpr int CH = 8 * NKG;                      // input channels per chunk (ring item)
     constexpr int NPL = F8 ? 2 : NSPLIT;             // planes per image
-    constexpr int NCT = NCW * 64, NPT = C::NPW * 64;   // consumer / producer threads
+    constexpr int NCWP = C::NCWP;                    // consumer waves that run (== NCW except for the f16 + fp8 64-channel tile)
+    constexpr int NCT = NCWP * 64, NPT = C::NPW * 64;  // consumer / producer threads
     constexpr int PLANE16 = NKG * NPIX;              // 16-byte units of one plane (hi or lo) of an image
     constexpr int IMG16 = NPL * PLANE16;             // ... of one ring slot
     static_assert(!F8 || (AB == 4 && RING == 2), "f16 + fp8 split: fp32 storage, two 32-channel images");
@@ -156,7 +167,7 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
     unsigned long long tr_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long tr_entry = WT_NOW();
 #endif
-    if (wave < NCW) {
+    if (wave < NCWP) {
         // =================================================================================== CONSUMERS
         __builtin_amdgcn_s_setprio(3);         // MFMA issue wins the per-SIMD arbitration against the producers' VALU stream
         const int wm = wave / WN, wn = wave % WN;
@@ -267,20 +278,25 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
         int k = 0, cc = 0, slot = 0;
         if constexpr (F8) {
             // ---------------------------------------------------------------- f16 + fp8 consumer loop (32 channels per item)
-            // Wave mapping of this form: wave w owns output channels 32 w .. 32 w + 31 of the tile for ALL its rows (FR = 10, or 5 in the
-            // small form) -- the same FR accumulators per wave as the 64-channel x 5-row mapping of the bf16x3 form, but HALF the weight
-            // fragments per tap (16 registers: two fp16 k-steps + one fp8 operand), so the weights are double-buffered: the next tap's set
-            // is requested at the start of the tap, a whole tap (>= 1280 cycles) ahead of its first use.  Measured on the first version of
-            // this loop (64 x 5 mapping, 8 fragment loads per tap 640-1100 cycles ahead): 16.1k cycles per item for 11.5k of MFMA issue,
-            // 12.6k without weight reloads, 12.3k with the loads and NO MFMAs -- an L2 round trip under this load is ~1400 cycles
-            // (profiles/r05_ws_f16f8_ablations.txt).  Activation fragments are each used by one MFMA only now; they stream through a
-            // rolling window ~224 cycles ahead (sched_barrier pins the issue order; hipcc reuses the registers of dead fragments).
-            // A tap is three passes over the FR accumulators: fp16 k-step 0, fp16 k-step 1, fp8 (both cross terms) -- per accumulator always
-            // in this order, in both forms of the kernel.
-            constexpr int FR = TR;                                   // rows (accumulators) per wave
+            // Wave mapping of this form: a wave owns ONE 32-channel block of the tile's output channels for FR rows -- all 10 rows of a
+            // 128-channel tile (four blocks, four waves), one 5-row band of a 64-channel tile (two blocks x two bands), the 5 rows of the
+            // small form -- i.e. FR accumulators and HALF the weight fragments per tap of the bf16x3 form's 64-channel x 5-row mapping
+            // (16 registers: two fp16 k-steps + one fp8 operand).  The weights are therefore kept NWS sets deep: the set of tap t + NWS - 1
+            // is requested at the start of tap t, >= 1280 cycles ahead of its first use.  Measured on the first version of this loop
+            // (64 x 5 mapping, 8 fragment loads per tap 640-1100 cycles ahead): 16.1k cycles per item for 11.5k of MFMA issue, 12.6k
+            // without weight reloads, 12.3k with the loads and NO MFMAs -- an L2 round trip under this load is ~1400 cycles
+            // (profiles/r05_ws_f16f8_ablations.txt); with the sets below: 12.5k.  Activation fragments are each used by one MFMA only; they
+            // stream through a rolling window LEAD cycles ahead (sched_barrier pins the issue order; hipcc reuses the registers of dead
+            // fragments).  A tap is three passes over the FR accumulators: fp16 k-step 0, fp16 k-step 1, fp8 (both cross terms) -- per
+            // accumulator always in this order, in every form of the kernel.
+            constexpr int CB = MT / 32;                              // 32-channel blocks of the tile
+            constexpr int NBW = NCWP / CB;                           // row bands that different waves own (2: the 64-channel tile)
+            constexpr int FR = TR / NBW;                             // rows (accumulators) per wave
             constexpr int NS = 3 * FR;                               // MFMA slots per tap
-            constexpr int LEAD = 224;                                // cycles between a fragment's ds_read and its MFMA
-            const int fm0 = wave * 32;
+            constexpr int NWS = FR >= 10 ? 2 : 3;                    // weight sets in flight (a tap is 128 FR cycles)
+            constexpr int LEAD = C::NT >= 768 ? 96 : 224;            // cycles between a fragment's ds_read and its MFMA (three waves per SIMD: 168 registers)
+            const int cbk = wave % CB, bnd = wave / CB;              // wave -> (channel block, band)
+            const int fm0 = cbk * 32;
             f32x16 facc[FR];
             const int wl_h = (kg_l * MTP + fm0 + l31) * 16;         // lane's row in a (tap, kg) segment of the fp16 plane
             const int wl_8 = (kg_l * 2 * MTP + fm0 + l31) * 16;     // ... of the fp8 plane: g = kg_l * 2 + q
@@ -299,21 +315,21 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
                 w.w8[4] = (int)q1[0]; w.w8[5] = (int)q1[1]; w.w8[6] = (int)q1[2]; w.w8[7] = (int)q1[3];
             };
             // start cycle of MFMA slot s of a tap (slots [0, FR): k-step 0, [FR, 2 FR): k-step 1, 32 cycles each; [2 FR, 3 FR): fp8, 64 each)
-            auto slot_t = [](int s2) constexpr { return s2 < 2 * FR ? 32 * s2 : 64 * FR + 64 * (s2 - 2 * FR); };
+            auto slot_t = [](int s2) { return s2 < 2 * FR ? 32 * s2 : 64 * FR + 64 * (s2 - 2 * FR); };
             constexpr int TAPC = 128 * FR;                           // cycles per tap
             // slot of THIS tap at whose start the fragment of slot u (u >= NS: slot u - NS of the next tap) is requested: the last slot
             // starting at least LEAD cycles before u does; -1: before this tap began (requested at the item's start instead)
-            auto issue_slot = [&](int u) constexpr {
+            auto issue_slot = [&](int u) {
                 const int tu = u < NS ? slot_t(u) : TAPC + slot_t(u - NS);
                 int r = -1;
                 for (int q = 0; q < NS; ++q)
                     if (slot_t(q) + LEAD <= tu) r = q;
                 return r;
             };
-            WSet wc, wn_;
-            const int xl0 = kg_l * NPIX + l31;                       // lane's fragment column in a plane (rows start at the tile's row 0)
+            WSet wq[NWS];                                            // wq[0]: the current tap's set; wq[k]: tap + k
+            const int xl0 = kg_l * NPIX + bnd * FR * HC + l31;       // lane's fragment column in a plane; rows start at this wave's band
             // tile epilogue of this mapping: bias, store, GroupNorm partial sums per 5-row band, written to s_red in the layout of the
-            // 64 x 5 mapping (wave row = band, fragment = this wave's channel block), so that finish_tile is common
+            // bf16x3 form (wave row = (channel-block pair) * WN + band, fragment = block inside the pair), so that finish_tile is common
             auto f8_epilogue = [&](int par) {
                 const int oxx = tl.tx * 32 + l31;
                 const int out_bytes = a.cout * HW * AB;
@@ -323,7 +339,8 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
                 const bool col_ok = oxx < a.Wout;
                 const float *bias_l = s_epi + par * MT + fm0 + 4 * kg_l;
 #pragma unroll
-                for (int band = 0; band < FR / 5; ++band) {
+                for (int lb = 0; lb < FR / 5; ++lb) {
+                    const int band = bnd * (FR / 5) + lb;             // 5-row band of the tile
                     float st1[4], st2[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { st1[q] = 0.f; st2[q] = 0.f; }
@@ -335,8 +352,8 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
                         const int soff = (ch0 + 8 * q) * HW * AB;
 #pragma unroll
                         for (int rr = 0; rr < 5; ++rr) {
-                            const int r = band * 5 + rr;
-                            const int oy = tl.ty * TR + r;
+                            const int r = lb * 5 + rr;
+                            const int oy = tl.ty * TR + band * 5 + rr;
                             if (oy >= a.Hout) continue;
                             float v[4];
 #pragma unroll
@@ -359,8 +376,7 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
                     wave_sums_transposed<8>(vals, tot);
                     if ((lane & 15) == 0) {
                         const int rw = lane >> 4;
-                        // s_red slot of (wave row, fragment) in the 64 x 5 layout: wave row index = (channel half of the tile) * WN + band
-                        const int wold = NCW == 1 ? 0 : (wave >> 1) * WN + band, mi = NCW == 1 ? 0 : (wave & 1);
+                        const int wold = (cbk / MF) * WN + band, mi = cbk % MF;
 #pragma unroll
                         for (int kk = 0; kk < 2; ++kk) {
                             const int vi = kk + 2 * (rw & 1) + 4 * (rw >> 1);
@@ -379,17 +395,23 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
                 const u32x4 *xh_p = s_img + slot * IMG16 + xl0;                                  // fp16 plane, k-step 0 (k-step 1: + 2 NPIX)
                 const u32x4 *x8_p = s_img + slot * IMG16 + PLANE16 + xl0 + kg_l * NPIX;          // fp8 plane: g = 2 kg_l (second half: + NPIX)
                 slot = slot + 1 == RING ? 0 : slot + 1;
+                const bool last_c = cc + 1 == nchunk;
+                const int ncn = last_c ? cc : cc + 1;               // (the last chunk re-requests its own first taps: never used)
+                // weights of tap index u of this item (u >= 9: tap u - 9 of the next chunk)
+                auto wload_tap = [&](WSet &w, int u) {
+                    if (u < 9) wload(w, cc, u / 3, u % 3, tl.cot);
+                    else wload(w, ncn, (u - 9) / 3, (u - 9) % 3, tl.cot);
+                };
                 if (cc == 0) {
-                    // a tile starts cold: its first weight fragments are requested here (one exposed round trip per tile)
-                    wload(wn_, 0, 0, 0, tl.cot);
+                    // a tile starts cold: its first weight sets are requested here (one exposed round trip per tile)
+#pragma unroll
+                    for (int q = 0; q + 1 < NWS; ++q) wload_tap(wq[q], q);
 #pragma unroll
                     for (int r = 0; r < FR; ++r)
 #pragma unroll
                         for (int e = 0; e < 16; ++e) facc[r][e] = 0.f;
                     for (int c = tid; c < MT; c += NCT) s_epi[par * MT + c] = a.bias[tl.cot * MT + c];
                 }
-                const bool last_c = cc + 1 == nchunk;
-                const int ncn = last_c ? cc : cc + 1;               // (the last chunk re-requests its own first tap: never used)
                 // activation fragments of the tap in flight: one variable per slot (dead ones are reused by the register allocator)
                 f16x8 fa[FR], fb[FR];
                 u32x4 f8l[FR], f8h[FR];
@@ -410,11 +432,8 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
                     for (int j = 0; j < 3; ++j) {
                         const bool last_t = st == 2 && j == 2;
                         const int nst = j == 2 ? st + 1 : st, nj = j == 2 ? 0 : j + 1;      // next tap inside the chunk
-                        wc = wn_;                                    // (a rename in the unrolled code; one copy on the loop's back edge)
-                        // next tap's weights, a whole tap ahead
-                        if (GTTS_WS_EXP != 1) {
-                            if (last_t) wload(wn_, ncn, 0, 0, tl.cot); else wload(wn_, cc, nst, nj, tl.cot);
-                        }
+                        // the set of tap + NWS - 1, NWS - 1 taps ahead
+                        if (GTTS_WS_EXP != 1) wload_tap(wq[NWS - 1], st * 3 + j + NWS - 1);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int s2 = 0; s2 < NS; ++s2) {
@@ -429,23 +448,26 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
                             const int r = s2 % FR;
 #if GTTS_WS_EXP == 5 && defined(__HIP_DEVICE_COMPILE__)
                             // (diagnostic builds, device pass only: on the host pass an asm with a "v" operand silently drops the kernel's stub)
-                            if (s2 < FR) asm volatile("" ::"v"(wc.a), "v"(fa[r]));
-                            else if (s2 < 2 * FR) asm volatile("" ::"v"(wc.b), "v"(fb[r]));
-                            else asm volatile("" ::"v"(wc.w8), "v"(f8l[r]), "v"(f8h[r]));
+                            if (s2 < FR) asm volatile("" ::"v"(wq[0].a), "v"(fa[r]));
+                            else if (s2 < 2 * FR) asm volatile("" ::"v"(wq[0].b), "v"(fb[r]));
+                            else asm volatile("" ::"v"(wq[0].w8), "v"(f8l[r]), "v"(f8h[r]));
                             if (false)
 #endif
                             if (s2 < FR) {
-                                facc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc.a, fa[r], facc[r], 0, 0, 0);
+                                facc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[0].a, fa[r], facc[r], 0, 0, 0);
                             } else if (s2 < 2 * FR) {
-                                facc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc.b, fb[r], facc[r], 0, 0, 0);
+                                facc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[0].b, fb[r], facc[r], 0, 0, 0);
                             } else {
                                 i32x8 b8;
                                 b8[0] = (int)f8l[r][0]; b8[1] = (int)f8l[r][1]; b8[2] = (int)f8l[r][2]; b8[3] = (int)f8l[r][3];
                                 b8[4] = (int)f8h[r][0]; b8[5] = (int)f8h[r][1]; b8[6] = (int)f8h[r][2]; b8[7] = (int)f8h[r][3];
-                                facc[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wc.w8, b8, facc[r], 0, 0, 0, 0, 0, 0);
+                                facc[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wq[0].w8, b8, facc[r], 0, 0, 0, 0, 0, 0);
                             }
                             __builtin_amdgcn_sched_barrier(0);
                         }
+                        // rotate the sets (renames in the unrolled code; copies only on the loop's back edge)
+#pragma unroll
+                        for (int q = 0; q + 1 < NWS; ++q) wq[q] = wq[q + 1];
                     }
                 }
                 [[maybe_unused]] const unsigned long long tw2 = WT_NOW();
@@ -870,7 +892,7 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
             WT_ADD(1, WT_NOW(), t1);
         };
         auto fin = [&](int i) {       // consumer item i - 1 closed a tile: its wave sums were written before this barrier
-            if (wave == NCW && i > 0 && i % nchunk == 0) {
+            if (wave == NCWP && i > 0 && i % nchunk == 0) {
                 const int kt = i / nchunk - 1;
                 finish_tile(decode(kt), kt & 1);
             }
@@ -920,12 +942,12 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
             }
         }
         lds_barrier();                                 // (F)
-        if (wave == NCW && nitems > 0) finish_tile(decode(my_tiles - 1), (my_tiles - 1) & 1);
+        if (wave == NCWP && nitems > 0) finish_tile(decode(my_tiles - 1), (my_tiles - 1) & 1);
     }
 #if GTTS_WS_TRACE
     if (tr_on && lane == 0 && (blockIdx.x >> 2) < 64) {
         tr_sum[4] = __builtin_amdgcn_s_memtime() - tr_entry;
-        for (int q = 0; q < 8; ++q) g_ws_trace[((blockIdx.x >> 2) * 8 + wave) * 8 + q] = tr_sum[q];
+        for (int q = 0; q < 8; ++q) g_ws_trace[((blockIdx.x >> 2) * 16 + wave) * 8 + q] = tr_sum[q];
     }
 #endif
 }
@@ -939,16 +961,22 @@ __global__ __launch_bounds__((WsCfg<WM, WN, MF, NF>::NT), 2) void conv3x3_ws_ker
 //   * 64 output channels: the same MFMA work needs twice the activation staging and has half the chunks per tile to spread
 //     the epilogue over; a 64 x 640 form of this kernel was level with conv_mfma.hip at 80 x 1024 (300 vs 306 us) and
 //     slower at 40 x 512 (92 vs 79 us).
+// LDS of the f16 + fp8 form: two 32-channel images + parameters (mt: 128, or 64 = the 12-wave form of the 64-channel tile)
+bool conv_ws_f8_fits(int cin, int pro, int mt) {
+    return ws_smem_bytes(12 * 34, 2, 2, cin, pro, mt, 2, mt == 128 ? 4 : 2, 4) <= (size_t)160 * 1024;
+}
 bool conv_ws_eligible(int mode, int c0, int c1, int cout, int pro, int epi, int nsplit, int f16f8) {
     const int cin = c0 + c1;
     if (!GTTS_WS || nsplit != 2) return false;
     if (mode != CONV_C3 || epi != EPI_STATS || (pro != PRO_MASK && pro != PRO_GN)) return false;
-    if (cout % 128 != 0) return false;
     if (f16f8) {
-        // GTTS_PREC_F16F8: 32-channel chunks (two per tile at least), weights in the f16 + fp8 format (conv_f16f8_ok), two images
-        if (!conv_f16f8_ok(mode, c0, c1, cout, pro, epi) || cin < 64) return false;
-        return ws_smem_bytes(12 * 34, 2, 2, cin, pro, 128, 2, 4, 4) <= (size_t)160 * 1024;
+        // GTTS_PREC_F16F8: 32-channel chunks (two per tile at least), weights in the f16 + fp8 format (conv_f16f8_ok), two images;
+        // 128-channel tiles, or the 64-channel tile (four consumer + eight producer waves)
+        if (cout % 128 != 0 && cout != 64) return false;
+        if (!conv_f16f8_ok(mode, c0, c1, cout, pro, epi, 1) || cin < 64) return false;
+        return conv_ws_f8_fits(cin, pro, cout == 64 ? 64 : 128);
     }
+    if (cout % 128 != 0) return false;
     if (cin % 16 != 0 || cin < 32 || (c1 != 0 && c0 % 16 != 0)) return false;
     // three activation images + the per-channel parameters must fit the CU's LDS
     return ws_smem_bytes(12 * 34, 2, 3, cin, pro, 128, 2, 4) <= (size_t)160 * 1024;
@@ -969,7 +997,7 @@ int conv_ws_nparts(int cout, int Hout, int Wout) {
 #endif
 bool conv_ws_small(int cout, int groups, int Hout, int Wout, int B) {
     if (groups <= 0 || cout / groups > 32) return false;
-    const long wgs = (long)B * ((Wout + 31) / 32) * ((Hout + 9) / 10) * (cout / 128);
+    const long wgs = (long)B * ((Wout + 31) / 32) * ((Hout + 9) / 10) * (cout % 128 == 0 ? cout / 128 : cout / 64);
     return wgs < GTTS_WS_SMALL_WGS;
 }
 
@@ -998,7 +1026,7 @@ static hipError_t launch_ws_ring(ConvArgs &a, hipStream_t st) {
     const size_t smem = ws_smem_bytes(C::NPIX, NPL, RING, a.cin, PRO, C::MT, MF, C::NCW, NKG);
     if (smem > (size_t)160 * 1024) return hipErrorInvalidValue;      // (conv_ws_eligible keeps such layers on conv_mfma.hip)
     // persistent workgroups: one per CU for the eight-wave form; the three-wave form fits two per CU (registers: 8 waves)
-    const int per_cu = C::NCW == 4 ? 1 : (int)std::min<size_t>(2, (size_t)160 * 1024 / smem);
+    const int per_cu = C::NT >= 512 ? 1 : (int)std::min<size_t>(2, (size_t)160 * 1024 / smem);
     const long ntiles = (long)a.B * a.tiles_x * a.tiles_y * (a.cout / C::MT);
     // (Measured and not kept: persistent workgroups on half of the CUs per launch -- grid 128 with two sub-batch streams, so
     // that the other stream's kernels find free CUs: 7.45 vs 7.48 ms per call; the dispatcher fills the same CUs first.)
@@ -1023,6 +1051,7 @@ static hipError_t launch_ws_pro(ConvArgs &a, hipStream_t st) {
     if (a.act_bf16 || a.nsplit != 2) return hipErrorInvalidValue;
     if (a.f16f8) {
         if (conv_ws_small(a.cout, a.groups, a.Hout, a.Wout, a.B)) return launch_ws_ring<1, 1, 1, PRO, 3, float>(a, st);
+        if (a.cout % 128 != 0) return launch_ws_ring<1, 2, 2, PRO, 3, float>(a, st);      // the 64-channel tile
         return launch_ws_ring<2, 2, 2, PRO, 3, float>(a, st);
     }
     if (conv_ws_small(a.cout, a.groups, a.Hout, a.Wout, a.B)) return launch_ws_ring<1, 1, 1, PRO, 2, float>(a, st);

@@ -197,7 +197,7 @@ static void add_block(gtts_plan *p, const std::string &pre, const std::string &t
                       int c1, int cout, int lvl, int pro, int psc, int psh, int tb_off, int *raw, int *sc, int *sh) {
     const int cin = c0 + c1;
     // GTTS_PREC_F16F8: eligible layers keep their weights in the f16 + fp8 format (pack kind 6; same size as kind 1)
-    const bool f8 = p->cfg.precision == GTTS_PREC_F16F8 && conv_f16f8_ok(CONV_C3, c0, c1, cout, pro, EPI_STATS);
+    const bool f8 = p->cfg.precision == GTTS_PREC_F16F8 && conv_f16f8_ok(CONV_C3, c0, c1, cout, pro, EPI_STATS, p->cfg.conv_ws);
     add_param(p, pre + "block.0.weight", {cout, cin, 3, 3}, f8 ? 6 : 1, cin, cout);
     add_param(p, pre + "block.0.bias", {cout}, 0);
     add_param(p, pre + "block.1.weight", {cout}, 0);
@@ -1390,7 +1390,8 @@ static std::string conv_kernel_name(int mode, int cin, int cout, int pro, int ep
     if (ws) {      // conv_ws.hip (launch_ws_pro)
         char wb[128];
         const bool sm = conv_ws_small(cout, groups, Ho, Wo, B);
-        snprintf(wb, sizeof wb, "gtts::conv3x3_ws_kernel<%d, %d, %d, 5, %d, %d, %s, %d>", sm ? 1 : 2, sm ? 1 : 2, sm ? 1 : 2, pro, f8 ? 3 : nsplit,
+        const int wm = sm ? 1 : (cout % 128 == 0 ? 2 : 1), wn = sm ? 1 : 2;       // (the f16 + fp8 64-channel tile: <1, 2, 2>)
+        snprintf(wb, sizeof wb, "gtts::conv3x3_ws_kernel<%d, %d, %d, 5, %d, %d, %s, %d>", wm, wn, sm ? 1 : 2, pro, f8 ? 3 : nsplit,
                  abf ? "__bf16" : "float", f8 ? 2 : 3);
         return wb;
     }
@@ -1450,7 +1451,7 @@ extern "C" int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, con
                                             plan->cfg.precision == GTTS_PREC_BF16_STORE, conv_small_tiles(o.mode, o.cout, Ho, Wo, B),
                                             plan->cfg.conv_ws && conv_ws_eligible(o.mode, o.c0, o.c1, o.cout, o.pro, o.epi, plan_nsplit(plan), plan->cfg.precision == GTTS_PREC_F16F8),
                                             B, (int)Ho, (int)Wo, plan->cfg.groups,
-                                            plan->cfg.precision == GTTS_PREC_F16F8 && conv_f16f8_ok(o.mode, o.c0, o.c1, o.cout, o.pro, o.epi));
+                                            plan->cfg.precision == GTTS_PREC_F16F8 && conv_f16f8_ok(o.mode, o.c0, o.c1, o.cout, o.pro, o.epi, plan->cfg.conv_ws));
                 break;
             }
             case OP_GNFIN: s_kernel = "gtts::gn_finalize_kernel"; break;

@@ -22,13 +22,15 @@ for _ in range(2):
     out = plan.estimator_forward(packed, x, mask, mu, t)
 torch.cuda.synchronize()
 lib = S._lib.lib()
-buf = (ctypes.c_ulonglong * 4096)()
-rc = lib.gtts_debug_trace_ws(buf, 4096)
-a = np.array(buf[:], dtype=np.float64).reshape(64, 8, 8)
+buf = (ctypes.c_ulonglong * 8192)()
+rc = lib.gtts_debug_trace_ws(buf, 8192)
+a = np.array(buf[:], dtype=np.float64).reshape(64, 16, 8)
 sel = a[:, 0, 4] > 0
 a = a[sel]
-print("rc", rc, "workgroups traced", a.shape[0], "(last traced launch of the call)")
-c, p = a[:, :4], a[:, 4:]
+ncw = 4
+npw = int((a[0, 4:, 4] > 0).sum())            # producer waves that wrote a total (4, or 8 in the 64-channel tile of the f16 + fp8 form)
+print("rc", rc, "workgroups traced", a.shape[0], "(last traced launch of the call); producer waves", npw)
+c, p = a[:, :ncw], a[:, ncw:ncw + npw]
 items = c[:, :, 3].mean()
 print("consumer: items %.0f  total %.0f cycles" % (items, c[:, :, 4].mean()))
 for i, n in enumerate(["image wait", "chunk loops", "tile epilogues"]):
