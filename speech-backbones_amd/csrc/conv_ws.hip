@@ -72,6 +72,17 @@ namespace gtts {
 #ifndef GTTS_WS64_NPW
 #define GTTS_WS64_NPW 8
 #endif
+// consumers of the f16 + fp8 form: weight sets in flight and fragment lead of the 64-channel tile (168 registers: 3 sets fit with a
+// 96-cycle lead, 2 sets with 160), fragment lead of the 128-channel tile
+#ifndef GTTS_WS64_NWS
+#define GTTS_WS64_NWS 3
+#endif
+#ifndef GTTS_WS64_LEAD
+#define GTTS_WS64_LEAD 96
+#endif
+#ifndef GTTS_WS_LEAD
+#define GTTS_WS_LEAD 160
+#endif
 template <int WM, int WN, int MF, int NF, int NKGT = 2>
 struct WsCfg {
     static constexpr int NCW = WM * WN;          // consumer wave ROWS x COLUMNS of the statistics layout: 4, 2 (64-channel tile) or 1
@@ -293,8 +304,8 @@ void conv3x3_ws_kernel(const ConvArgs a) {
             constexpr int NBW = NCWP / CB;                           // row bands that different waves own (2: the 64-channel tile)
             constexpr int FR = TR / NBW;                             // rows (accumulators) per wave
             constexpr int NS = 3 * FR;                               // MFMA slots per tap
-            constexpr int NWS = FR >= 10 ? 2 : 3;                    // weight sets in flight (a tap is 128 FR cycles)
-            constexpr int LEAD = C::NT >= 768 ? 96 : 224;            // cycles between a fragment's ds_read and its MFMA (three waves per SIMD: 168 registers)
+            constexpr int NWS = FR >= 10 ? 2 : GTTS_WS64_NWS;        // weight sets in flight (a tap is 128 FR cycles)
+            constexpr int LEAD = C::NT >= 768 ? GTTS_WS64_LEAD : GTTS_WS_LEAD;   // cycles between a fragment's ds_read and its MFMA (three waves per SIMD: 168 registers)
             const int cbk = wave % CB, bnd = wave / CB;              // wave -> (channel block, band)
             const int fm0 = cbk * 32;
             f32x16 facc[FR];

@@ -252,6 +252,25 @@ class ScoreLoss(torch.autograd.Function):
 
 FORCE_TORCH = False      # measurement switch (bench.py train_step): route every op to stock PyTorch-ROCm kernels
 
+# How many tensor-sized ops of the training path ran on the gtts:: kernels and how many fell back to stock torch ops because a gate
+# (shape, dtype, device, channel multiple) failed.  A fallback is correct but slow, and silent otherwise: callers / tests read
+# `op_counts()` after a step (tests/test_gpu_training.py asserts (n, 0) on the reference's shapes).
+_COUNTS = {"hip_ops": 0, "torch_fallback_ops": 0}
+
+
+def reset_op_counts():
+    _COUNTS["hip_ops"] = 0
+    _COUNTS["torch_fallback_ops"] = 0
+
+
+def op_counts():
+    return _COUNTS["hip_ops"], _COUNTS["torch_fallback_ops"]
+
+
+def _count(hip):
+    if not FORCE_TORCH:
+        _COUNTS["hip_ops" if hip else "torch_fallback_ops"] += 1
+
 
 def _hip_conv_ok(v, conv):
     # (shape: the kernels address one call's tensors with 32-bit byte offsets -- oversize batches / crops take the torch path
@@ -266,7 +285,9 @@ def _conv1x1(v, m, conv):
     if (not FORCE_TORCH and v.is_cuda and v.dtype == torch.float32 and conv.kernel_size == (1, 1) and
             backend().conv1x1_supported(conv.in_channels, conv.out_channels, need_dgrad=v.requires_grad,
                                         shape=(v.shape[0], v.shape[2], v.shape[3]))):
+        _count(True)
         return MaskedConv1x1.apply(v.contiguous(), m, conv.weight, conv.bias)
+    _count(False)
     return F.conv2d(v if m is None else v * m, conv.weight, conv.bias)
 
 
@@ -284,12 +305,16 @@ def _conv_gn_mish(blk, v, m, tb=None, v1=None):
     if v1 is not None and not (_hip_conv_ok(v, conv) and v.shape[1] % 64 == 0):
         v, v1 = torch.cat((v, v1), dim=1), None
     if _hip_conv_ok(v, conv):
+        _count(True)
         y = MaskedConv3x3.apply(v.contiguous(), m, conv.weight, conv.bias, None if v1 is None else v1.contiguous())
     else:
+        _count(False)
         y = F.conv2d(v * m, conv.weight, conv.bias, padding=1)
     if _hip(y) and y.dim() == 4 and y.shape[1] % norm.num_groups == 0:
+        _count(True)
         return GnMishMask.apply(y.contiguous(), m, norm.weight, norm.bias, norm.num_groups, norm.eps,
                                 None if tb is None else tb.contiguous())
+    _count(False)
     y = F.group_norm(y, norm.num_groups, norm.weight, norm.bias, norm.eps)
     y = _mish(y) * m
     return y if tb is None else y + tb[:, :, None, None]
@@ -320,9 +345,11 @@ def resnet(rb, v, m, temb, v1=None, tb=None):
         elif _hip(v) and backend().conv1x1_supported(v.shape[1], rc.out_channels) and backend().conv1x1_supported(v1.shape[1], rc.out_channels):
             # a 1x1 convolution of a concatenation is the sum of the convolutions of its parts with the weight's column blocks
             c0 = v.shape[1]
+            _count(True)
             r = MaskedConv1x1.apply(v.contiguous(), m, rc.weight[:, :c0].contiguous(), rc.bias)
             r = MaskedResidualAdd.apply(r, MaskedConv1x1.apply(v1.contiguous(), m, rc.weight[:, c0:].contiguous(), None), None)
         else:
+            _count(False)
             r = F.conv2d(torch.cat((v, v1), dim=1) * m, rc.weight, rc.bias)
         return MaskedResidualAdd.apply(h, r.contiguous(), None) if _hip(h) else h + r
     if v1 is not None:
@@ -437,6 +464,8 @@ def estimator(est, x, mask, mu, t, spk=None):
     v = _conv_gn_mish(est.final_block, v, m)
     fc = est.final_conv
     if _hip(v) and fc.out_channels == 1:
+        _count(True)
         return FinalConv.apply(v.contiguous(), m, fc.weight, fc.bias).squeeze(1)
+    _count(False)
     out = F.conv2d(v * m, fc.weight, fc.bias)
     return (out * m).squeeze(1)

@@ -265,6 +265,30 @@ def test_full_size_properties(S, dev, conv_ws):
     assert relerr(a[3:4].cpu(), ref) <= REL
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "f16f8"])
+def test_large_ragged_batch_b32_t2048(S, dev, prec):
+    """Twice the headline batch at twice its length, ragged (workspace sizing, the 32-bit buffer-descriptor offsets of the
+    convolution epilogues -- a level-0 tensor is 32 x 64 x 80 x 2048 x 4 B = 1.34 GB, a sample's slice 42 MB --, the sub-batch
+    split, persistent-kernel tile walks over 2 x 64 column tiles): finite, masked frames exactly zero, and B = 32 == 16 + 16
+    bit for bit."""
+    sd = O.make_estimator_state(seed=0)
+    plan = S.Plan(precision={"bf16x3": S.PREC_BF16X3, "f16f8": S.PREC_F16F8}[prec])
+    blob = plan.pack(sd, dev)
+    B, T = 32, 2048
+    inp = O.make_inputs(B, T, seed=4321, ragged=True)
+    z, m, mu = inp["z"].to(dev), inp["mask"].to(dev), inp["mu"].to(dev)
+    a = plan.reverse_diffusion(blob, z, m, mu, 2)
+    assert torch.isfinite(a).all()
+    assert float((a * (1 - m)).abs().max()) == 0.0
+    lo = plan.reverse_diffusion(blob, z[:16].contiguous(), m[:16].contiguous(), mu[:16].contiguous(), 2)
+    hi = plan.reverse_diffusion(blob, z[16:].contiguous(), m[16:].contiguous(), mu[16:].contiguous(), 2)
+    assert torch.equal(a, torch.cat([lo, hi], 0))
+    # one utterance of the big batch against the CPU oracle (B = 1, two steps: seconds of CPU time)
+    i = 7
+    ref = O.reverse_diffusion(sd, inp["z"][i:i + 1], inp["mask"][i:i + 1], inp["mu"][i:i + 1], 2)
+    assert relerr(a[i:i + 1].cpu(), ref) <= REL
+
+
 @both_convs
 def test_batch_size_does_not_change_results(S, dev, conv_ws):
     """Small launches tile the deep 3x3 layers with half-height tiles (conv_small_tiles): at T = 1024 one utterance alone

@@ -274,8 +274,14 @@ def test_estimator_parameter_gradients_match_cpu_autograd(S, dev):
 
     lc = loss_of(cpu, torch.device("cpu"))
     lc.backward()
+    TO = importlib.import_module("speech-backbones_amd.model._train_ops")
+    TO.reset_op_counts()
     lg = loss_of(gpu, dev)
     lg.backward()
+    # the training path may not leave the HIP kernels silently: 25 Block convolutions + 25 GroupNorm/Mish + the 1x1 res_conv /
+    # attention projections that go through the gate + the final conv; zero torch fallbacks on the reference's shapes
+    hip_ops, fallbacks = TO.op_counts()
+    assert fallbacks == 0 and hip_ops >= 54, (hip_ops, fallbacks)
     assert abs(float(lg.detach()) - float(lc.detach())) <= 1e-5 * abs(float(lc.detach()))
     worst = ("", 0.0)
     n = 0
