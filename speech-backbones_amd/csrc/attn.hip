@@ -18,9 +18,7 @@
 #include "kernels.h"
 
 // heads per workgroup of the per-head context kernel (C >= 128): see attn_ctx_kernel
-#ifndef GTTS_ATTN_HPW
-#define GTTS_ATTN_HPW 2
-#endif
+// (GTTS_ATTN_HPW: heads per workgroup of the C >= 128 context kernel -- kernels.h, shared with the kernel-name table of plan.hip)
 
 namespace gtts {
 

@@ -479,7 +479,8 @@ static inline hipError_t launch_conv1d(C1Args a, int mode, int K, int dil, hipSt
     a.ls = 0;
     while ((1 << a.ls) < a.S) ++a.ls;
     if ((1 << a.ls) != a.S) return hipErrorInvalidValue;
-    if ((size_t)a.cout * a.Lin * a.S >= ((size_t)1 << 31)) return hipErrorInvalidValue;
+    // (the buffer-descriptor epilogues address a sample's OUTPUT with 32-bit byte offsets: cout * Lout * 4 bytes, Lout = Lin * S)
+    if ((size_t)a.cout * a.Lin * a.S * 4 >= ((size_t)1 << 31)) return hipErrorInvalidValue;
     if (a.cin % 16 != 0 || (size_t)a.cin * a.Lin * 4 >= ((size_t)1 << 31)) return hipErrorInvalidValue;   // buffer-load staging
     return g.tps == 3 ? launch_c1_t<3>(a, st) : launch_c1_t<4>(a, st);
 }

@@ -68,6 +68,11 @@ bool conv_rowpair_stats(int mode, int cout, int Hout, int Wout);
 bool conv_small_tiles(int mode, int cout, int Hout, int Wout, int B);
 
 // ---- attn.hip  (LinearAttention, diffusion.py:82-100, folded: see attn.hip header)
+// heads per workgroup of attn_ctx_kernel (C >= 128): two heads share one staged x tile.  A build-time choice that appears in the
+// kernel's template arguments, hence in the names gtts_plan_op_info reports for the rocprofv3 / traffic.json joins.
+#ifndef GTTS_ATTN_HPW
+#define GTTS_ATTN_HPW 2
+#endif
 constexpr int ATTN_KCH = 2;                 // 16-channel chunks per LDS stage of the k/v projection
 constexpr int ATTN_REC = 32 + 32 + 32 * 32; // floats per partial record: m[32], Z[32], ctx[32][32]
 struct AttnGeom {

@@ -209,9 +209,14 @@ hipError_t launch_mas(const float *value, const float *mask, const int *t_x, con
                       unsigned char *scratch, int b, int tx, int ty, hipStream_t st) {
     hipError_t e = hipMemsetAsync(path, 0, (size_t)b * tx * ty * sizeof(int), st);
     if (e != hipSuccess) return e;
-    if (tx <= 256) return launch_mas_wave<4, 32>(value, mask, t_x, t_y, path, scratch, b, tx, ty, st);
-    if (tx <= 512) return launch_mas_wave<8, 32>(value, mask, t_x, t_y, path, scratch, b, tx, ty, st);
-    if (tx <= 1024) return launch_mas_wave<16, 16>(value, mask, t_x, t_y, path, scratch, b, tx, ty, st);
+    // one DP wave per sample (66-132 KB of LDS); if the device refuses that much dynamic LDS the column-sweep kernel below
+    // (2 tx floats) computes the same path -- both restate core.pyx:9-35 cell for cell
+    e = hipErrorInvalidValue;
+    if (tx <= 256) e = launch_mas_wave<4, 32>(value, mask, t_x, t_y, path, scratch, b, tx, ty, st);
+    else if (tx <= 512) e = launch_mas_wave<8, 32>(value, mask, t_x, t_y, path, scratch, b, tx, ty, st);
+    else if (tx <= 1024) e = launch_mas_wave<16, 16>(value, mask, t_x, t_y, path, scratch, b, tx, ty, st);
+    if (e == hipSuccess) return e;
+    (void)hipGetLastError();
     const size_t smem = (size_t)2 * tx * sizeof(float);
     if (smem > 160 * 1024) return hipErrorInvalidValue;
     if (smem > 48 * 1024) {

@@ -1470,8 +1470,8 @@ extern "C" int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, con
                 if (attn_head_per_wave(o.C))
                     snprintf(nb, sizeof nb, "gtts::attn_ctx64_kernel<%d, %s>", plan_nsplit(plan), abf ? "__bf16" : "float");
                 else
-                    snprintf(nb, sizeof nb, "gtts::attn_ctx_kernel<%d, %d, %s, 2>", plan_nsplit(plan), o.C % 32 == 0 ? 1 : 0,
-                             abf ? "__bf16" : "float");
+                    snprintf(nb, sizeof nb, "gtts::attn_ctx_kernel<%d, %d, %s, %d>", plan_nsplit(plan), o.C % 32 == 0 ? 1 : 0,
+                             abf ? "__bf16" : "float", GTTS_ATTN_HPW);
                 s_kernel = nb;
                 fl = 2.0 * B * Hi * Wi * (256.0 * o.C + 128.0 * 32);
                 by = ab * B * o.C * Hi * Wi; break;

@@ -429,8 +429,8 @@ def estimator(est, x, mask, mu, t, spk=None):
     if not FORCE_TORCH and x.is_cuda:
         be = backend()
         be.new_pack_generation()               # packed weight copies live for this call's forward + backward only ...
-        if torch.is_grad_enabled():
-            be.prepack(_pack_specs(est))       # ... and all of them are made here, in one launch
+        be.prepack(_pack_specs(est))           # ... and all of them are made here, in one launch (also under no_grad: a validation
+                                               # call would otherwise pack ~45 weights one by one, each with its own allocation)
     temb = time_embedding(est, t)
     planes = [mu, x]
     if est.n_spks >= 2:
