@@ -48,7 +48,7 @@ enum {
 
 /* precision of the dense contractions (3x3 / 1x1 / transposed convs, attention products) */
 enum {
-    GTTS_PREC_BF16X3 = 0,    /* split-bf16 (hi/lo, 3 MFMAs, fp32 accumulate): fp32-grade accuracy (default) */
+    GTTS_PREC_BF16X3 = 0,    /* split-bf16 (hi/lo, 3 MFMAs, fp32 accumulate): fp32-grade accuracy                 */
     GTTS_PREC_BF16 = 1,      /* single bf16 MFMA, fp32 accumulate, fp32 activation storage                   */
     GTTS_PREC_BF16_STORE = 2,/* BASELINE.json config 3 as written: single bf16 MFMA, fp32 accumulate, and every
                                 activation tensor of the U-Net stored as bf16 (weights are bf16 already); GroupNorm
@@ -83,12 +83,13 @@ typedef struct gtts_unet_cfg {
     int c_dim;           /* 256: speaker-embedding width                                                 */
     double vc_beta_min;  /* DiffVC schedule scalars are Python doubles in the reference (diffusion.py:120-149) */
     double vc_beta_max;
-    /* ---- ABI 3: which kernel runs the Block 3x3 convolutions of 128-channel-and-wider layers in GTTS_PREC_BF16X3 ---- */
+    /* ---- ABI 3: which kernel runs the Block 3x3 convolutions of 128-channel-and-wider layers in GTTS_PREC_BF16X3 / F16F8 ---- */
     int conv_ws;         /* 0: uniform-wave kernel (conv_mfma.hip; overlaps with other streams' kernels: best with three
-                            sub-batch streams on the Grad-TTS dim-64 network).  1: persistent wave-specialised kernel
+                            sub-batch streams in BF16X3 on the Grad-TTS dim-64 network).  1: persistent wave-specialised kernel
                             (conv_ws.hip; a higher MFMA rate per launch, but it fills every CU's registers: best where these
-                            convolutions dominate, e.g. the DiffVC dim-256 decoder).  Either way results do not depend on
-                            the batch split; the two modes agree to fp32 rounding of the GroupNorm statistics. */
+                            convolutions dominate -- the DiffVC dim-256 decoder -- and in GTTS_PREC_F16F8, where it also runs the
+                            64-channel layers, unsplit).  Either way results do not depend on the batch split; the two modes
+                            agree to fp32 rounding of the GroupNorm statistics. */
 } gtts_unet_cfg;
 
 typedef struct gtts_plan gtts_plan;   /* host-side metadata only */

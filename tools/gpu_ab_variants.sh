@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 5, visit J: same-box A/B of the default (f16f8, all eligible layers on the persistent kernel, 8 producer waves on the 64-channel tile)
+# Same-box alternating A/B of library variants on the headline bench, plus the batch-size sweep that picks the drop-in module's plan.
+# Variant libraries:  bash tools/build_variants.sh ws64off "-DGTTS_F8_WS64=0" npw4 "-DGTTS_WS64_NPW=4"
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
 run() { n=$1; shift
   timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras "$@" > gpurun_out/r05j_bench_$n.json 2> gpurun_out/r05j_tables_$n.txt

@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 5, visit K: the whole GPU suite on the new defaults, the driver's default bench line, A/B of two consumer pipeline depths
+# The whole GPU suite + smoke, then alternating A/B of consumer pipeline depths, then the driver's default bench line.
+# Variant libraries:  bash tools/build_variants.sh lead160 "-DGTTS_WS_LEAD=160" w64n2 "-DGTTS_WS64_NWS=2 -DGTTS_WS64_LEAD=160"
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -1
 timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/r05k_pytest_gpu.txt 2>&1

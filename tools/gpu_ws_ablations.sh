@@ -1,5 +1,7 @@
 #!/bin/bash
-# round 5, visit D: timing ablations of the f16 + fp8 persistent kernel (results of the ablated builds are WRONG by design)
+# Timing ablations of the f16 + fp8 persistent kernel (results of the ablated builds are WRONG by design).  Variant libraries:
+#   bash tools/build_variants.sh wstrace "-DGTTS_DIAG -DGTTS_WS_TRACE=1" wsx1 "-DGTTS_DIAG -DGTTS_WS_TRACE=1 -DGTTS_WS_EXP=1" ... (EXP 1, 2, 3, 5)
+# Output of round 5: profiles/r05_ws_f16f8_ablations.txt
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
 for v in wstrace wsx1 wsx2 wsx3 wsx4 wsx5; do
   export GTTS_LIB=$PWD/speech-backbones_amd/libgtts_$v.so

@@ -1,4 +1,4 @@
-"""profiles/traffic.json from the two PMC summaries of tools/pmc_traffic.sh (FETCH_SIZE, WRITE_SIZE; KB per kernel name).
+"""profiles/traffic.json from the two PMC summaries of tools/gpu_profiles_r05.sh (FETCH_SIZE, WRITE_SIZE; KB per kernel name).
 
 bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / launches.  The factor 2 on reads is the gfx950 rocprofv3
 correction of MI355X_MICROARCH.md (HBM section), re-checked here on kernels with known byte counts (prep_input,
