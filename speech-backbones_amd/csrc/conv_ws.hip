@@ -77,6 +77,10 @@ namespace gtts {
 #ifndef GTTS_WS64_NWS
 #define GTTS_WS64_NWS 3
 #endif
+// producer waves of the small-launch form in f16 + fp8 (one consumer wave; bf16x3: two)
+#ifndef GTTS_WS_SMALL_NPW8
+#define GTTS_WS_SMALL_NPW8 2
+#endif
 #ifndef GTTS_WS64_LEAD
 #define GTTS_WS64_LEAD 96
 #endif
@@ -89,7 +93,7 @@ struct WsCfg {
     // waves that actually run: the f16 + fp8 form (NKGT == 4) maps one wave to a 32-channel block (x a 5-row band for the 64-channel
     // tile), so the 64-channel tile still has four consumers; it takes eight producer waves (twice the staging per MFMA)
     static constexpr int NCWP = (NKGT == 4 && WM == 1 && WN == 2) ? 4 : NCW;
-    static constexpr int NPW = NCW == 1 ? 2 : ((NKGT == 4 && WM == 1 && WN == 2) ? GTTS_WS64_NPW : NCW);   // producer waves (small form: a 32-channel
+    static constexpr int NPW = NCW == 1 ? (NKGT == 4 ? GTTS_WS_SMALL_NPW8 : 2) : ((NKGT == 4 && WM == 1 && WN == 2) ? GTTS_WS64_NPW : NCW);   // producer waves (small form: a 32-channel
                                                      // consumer tile takes 4.3k cycles per chunk, one producer wave needs 6k to stage it)
     static constexpr int NT = (NCWP + NPW) * 64; // threads per workgroup
     static constexpr int MT = WM * MF * 32;      // output channels per workgroup

@@ -3,7 +3,7 @@ diffusion.py:17-106) and `Diffusion` with the pf / em / ml samplers (diffusion.p
 signatures, parameter names and shapes (117 794 599 decoder parameters at dim_unet=256).
 
 Sampling (torch.no_grad) runs on the HIP kernels through the C ABI (gtts_vc_*); there is no CPU fallback.  Training
-(loss_t / compute_loss, autograd) composes stock PyTorch-ROCm ops over the same parameters.
+(loss_t / compute_loss, autograd) runs the score network's trunk on the gtts:: training kernels (GradLogPEstimator._forward_train).
 """
 import math
 
@@ -80,39 +80,79 @@ class GradLogPEstimator(BaseModule):
             self._hip_key = key
         return self._hip_blob
 
-    def _forward_torch(self, x, x_mask, mean, ref, ref_mask, c, t):
-        """Autograd composition (training only), diffusion.py:61-106."""
+    def _first_resnet(self, rb, v2, cexp, m, temb):
+        """ResnetBlock.forward (DiffVC/model/modules.py:75-103) on cat(v2, cexp) -- the stacked (mean, x) planes and the condition
+        vector broadcast over the mel plane, 2 + dim_cond channels (diffusion.py:74-76) -- without the concatenated tensor: both of
+        its convolutions are linear in their input, so each is the sum of a 2-channel convolution (the first-layer kernels of the
+        Grad-TTS network: no data gradient wanted) and a dim_cond-channel one with the weight's column blocks."""
+        be = backend()
+        conv, norm, rc = rb.block1.block[0], rb.block1.block[1], rb.res_conv
+        nc, co = cexp.shape[1], conv.out_channels
+        shape = (v2.shape[0], v2.shape[2], v2.shape[3])
+        ok = (T._hip(v2) and not v2.requires_grad and
+              be.conv3x3_supported(2, co, need_dgrad=False, shape=shape) and be.conv3x3_supported(nc, co, need_dgrad=True, shape=shape) and
+              be.conv1x1_supported(2, co, need_dgrad=False, shape=shape) and be.conv1x1_supported(nc, co, need_dgrad=True, shape=shape))
+        if not ok:
+            T._count(False)
+            return T.resnet(rb, torch.cat((v2, cexp), 1), m, temb)
+        lin = rb.mlp[1]
+        tb = torch.nn.functional.linear(T._mish(temb), lin.weight, lin.bias)
+        T._count(True)
+        y = T.MaskedConv3x3.apply(v2.contiguous(), m, conv.weight[:, :2].contiguous(), conv.bias, None)
+        zero_b = torch.zeros(co, dtype=v2.dtype, device=v2.device)      # (the 3x3 entry point takes a bias pointer; the bias rides with the first part)
+        y = T.MaskedResidualAdd.apply(y, T.MaskedConv3x3.apply(cexp, m, conv.weight[:, 2:].contiguous(), zero_b, None), None)
+        T._count(True)
+        h = T.GnMishMask.apply(y.contiguous(), m, norm.weight, norm.bias, norm.num_groups, norm.eps, tb.contiguous())
+        h = T._conv_gn_mish(rb.block2, h, m)
+        T._count(True)
+        r = T.MaskedConv1x1.apply(v2.contiguous(), m, rc.weight[:, :2].contiguous(), rc.bias)
+        r = T.MaskedResidualAdd.apply(r, T.MaskedConv1x1.apply(cexp, m, rc.weight[:, 2:].contiguous(), None), None)
+        return T.MaskedResidualAdd.apply(h, r.contiguous(), None)
+
+    def _forward_train(self, x, x_mask, mean, ref, ref_mask, c, t):
+        """Autograd composition (training: DiffVC/train_dec.py:90-103 -> Diffusion.compute_loss -> loss_t, diffusion.py:207-226;
+        this is GradLogPEstimator.forward, diffusion.py:61-106).  The trunk -- every 3x3 / 1x1 / resampling convolution with its
+        data and weight gradients, GroupNorm + Mish + time term, the LinearAttention core, the residual adds, the final conv -- runs
+        on the gtts:: training kernels of the Grad-TTS network (model/_train_ops.py; channel counts 64 or multiples of 128, i.e. every
+        dim_base that is one); the condition path (time MLP, RefBlock's InstanceNorm + GLU stack on the one-channel reference mel,
+        cond_block) composes stock torch ops: ~5 % of the step's FLOPs.  CPU tensors take the same code on stock ops."""
+        if not T.FORCE_TORCH and x.is_cuda:
+            be = backend()
+            be.new_pack_generation()
+            be.prepack(T._pack_specs(self))
         condition = self.time_pos_emb(t)
         temb = self.mlp(condition)
-        v = torch.stack([mean, x], 1)
+        v2 = torch.stack([mean, x], 1)
         m0 = x_mask.unsqueeze(1)
         if self.use_ref_t:
             condition = torch.cat([condition, self.ref_block(ref, ref_mask.unsqueeze(1), temb)], 1)
         condition = self.cond_block(torch.cat([condition, c], 1))
-        v = torch.cat([v, condition[:, :, None, None].expand(-1, -1, v.shape[2], v.shape[3])], 1)
+        cexp = condition[:, :, None, None].expand(-1, -1, v2.shape[2], v2.shape[3]).contiguous()
         skips, pyramid = [], [m0]
+        first = True
         for r1, r2, att, down in self.downs:
             m = pyramid[-1]
-            v = T.attention(att, T.resnet(r2, T.resnet(r1, v, m, temb), m, temb))
+            v = self._first_resnet(r1, v2, cexp, m, temb) if first else T.resnet(r1, v, m, temb)
+            first = False
+            v = T.attention(att, T.resnet(r2, v, m, temb))
             skips.append(v)
             if not isinstance(down, torch.nn.Identity):
-                v = down.conv(v * m)
-            pyramid.append(m[..., ::2])
+                v = T._resample(v, m, down.conv, False)
+            pyramid.append(m[..., ::2].contiguous())
         pyramid.pop()
         m = pyramid[-1]
         v = T.resnet(self.mid_block2, T.attention(self.mid_attn, T.resnet(self.mid_block1, v, m, temb)), m, temb)
         for r1, r2, att, up in self.ups:
             m = pyramid.pop()
-            v = torch.cat((v, skips.pop()), dim=1)
-            v = T.attention(att, T.resnet(r2, T.resnet(r1, v, m, temb), m, temb))
-            v = up.conv(v * m)
+            v = T.resnet(r1, v, m, temb, v1=skips.pop())            # (torch.cat((v, skip), 1) read in place)
+            v = T.attention(att, T.resnet(r2, v, m, temb))
+            v = T._resample(v, m, up.conv, True)
         v = T._conv_gn_mish(self.final_block, v, m0)
-        out = torch.nn.functional.conv2d(v * m0, self.final_conv.weight, self.final_conv.bias)
-        return (out * m0).squeeze(1)
+        return T.final_conv(self.final_conv, v, m0)
 
     def forward(self, x, x_mask, mean, ref, ref_mask, c, t):
         if torch.is_grad_enabled():
-            return self._forward_torch(x, x_mask, mean, ref, ref_mask, c, t)
+            return self._forward_train(x, x_mask, mean, ref, ref_mask, c, t)
         if not x.is_cuda:
             raise RuntimeError("GradLogPEstimator sampling runs on the MI355X HIP kernels only; got a %s tensor "
                                "(there is no CPU fallback)" % x.device)

@@ -462,7 +462,11 @@ def estimator(est, x, mask, mu, t, spk=None):
         v = _resample(v, m, up.conv, True)
     m = mask[:, None]
     v = _conv_gn_mish(est.final_block, v, m)
-    fc = est.final_conv
+    return final_conv(est.final_conv, v, m)
+
+
+def final_conv(fc, v, m):
+    """final_conv(v * mask) * mask, squeezed (diffusion.py:214-216; DiffVC/model/diffusion.py:104-106)."""
     if _hip(v) and fc.out_channels == 1:
         _count(True)
         return FinalConv.apply(v.contiguous(), m, fc.weight, fc.bias).squeeze(1)
