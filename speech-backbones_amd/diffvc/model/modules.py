@@ -45,11 +45,25 @@ class RefBlock(BaseModule):
         self.block32 = _conv_in_glu(4 * base, 8 * base)
         self.final_conv = torch.nn.Conv2d(4 * base, out_dim, 1)
 
+    @staticmethod
+    def _block(blk, y, mask):
+        """conv3x3(y * mask) -> InstanceNorm -> GLU (DiffVC/model/modules.py:140-157).  Training on the GPU: the convolution (forward, data
+        and weight gradient) on the gtts:: training kernels where their tiles allow (64 or a multiple of 128 channels on both sides:
+        block22 / block31 / block32 = 90 % of RefBlock's FLOPs at out_dim 128); InstanceNorm + GLU stay torch ops."""
+        from ...model import _train_ops as T
+        from ...model._backend import backend
+        conv = blk[0]
+        if (torch.is_grad_enabled() and T._hip(y) and y.dim() == 4 and
+                backend().conv3x3_supported(conv.in_channels, conv.out_channels, need_dgrad=True, shape=(y.shape[0], y.shape[2], y.shape[3]))):
+            T._count(True)
+            return blk[2](blk[1](T.MaskedConv3x3.apply(y.contiguous(), mask, conv.weight, conv.bias, None)))
+        return blk(y * mask)
+
     def forward(self, x, mask, time_emb):
-        y = self.block12(self.block11(x * mask) * mask)
+        y = self._block(self.block12, self._block(self.block11, x, mask), mask)
         y = y + self.mlp1(time_emb)[:, :, None, None]
-        y = self.block22(self.block21(y * mask) * mask)
+        y = self._block(self.block22, self._block(self.block21, y, mask), mask)
         y = y + self.mlp2(time_emb)[:, :, None, None]
-        y = self.block32(self.block31(y * mask) * mask)
+        y = self._block(self.block32, self._block(self.block31, y, mask), mask)
         y = self.final_conv(y * mask)
         return (y * mask).sum((2, 3)) / (mask.sum((2, 3)) * x.shape[2])
