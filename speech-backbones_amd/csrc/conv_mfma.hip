@@ -1086,6 +1086,10 @@ static hipError_t launch_prec(const ConvArgs &a, hipStream_t st) {
     }
     // ragged channel counts only occur on first layers (stacked input, 1-channel reference): PRO_MASK variants
     constexpr bool ragged_ok = PRO == PRO_MASK && (MODE == CONV_C3 || MODE == CONV_P1);
+#ifdef GTTS_LEAN      // A/B builds: a code object without the single-pass bf16 / bf16-storage instances (do unlaunched kernels cost time?)
+    if (a.act_bf16 || a.nsplit == 1) return hipErrorInvalidValue;
+#endif
+#ifndef GTTS_LEAN
     if (a.act_bf16) {
         // bf16 storage (BASELINE config 3): single-pass bf16 MFMA only, Grad-TTS op set only (no InstanceNorm-GLU convs)
         if constexpr (PRO != PRO_IGLU && !(MODE == CONV_C3 && EPI == EPI_PLAIN)) {
@@ -1095,6 +1099,7 @@ static hipError_t launch_prec(const ConvArgs &a, hipStream_t st) {
         }
         return hipErrorInvalidValue;
     }
+#endif
     if constexpr (GTTS_PRIV && MODE == CONV_C3 && PRO != PRO_IGLU) {
         // bf16x3 3x3 convolutions on whole chunks: private weight slices (same workgroup tiles, waves re-arranged to
         // 32 channels x 4 rows each): 128 x (4 x 32) as 4 x 1 waves, 64 x (8 x 32) as 2 x 2 waves
@@ -1103,12 +1108,17 @@ static hipError_t launch_prec(const ConvArgs &a, hipStream_t st) {
             else return launch_cfg<MODE, 2, 2, 1, 1, PRO, EPI, 2, 1, float, 4, 1>(a, st);
         }
     }
+#ifdef GTTS_LEAN
+    if (fullc) return launch_cfg<MODE, WM, WN, MF, 1, PRO, EPI, 2, 1>(a, st);
+    if constexpr (ragged_ok) return launch_cfg<MODE, WM, WN, MF, 1, PRO, EPI, 2, 0>(a, st);
+#else
     if (fullc)
         return a.nsplit > 1 ? launch_cfg<MODE, WM, WN, MF, 1, PRO, EPI, 2, 1>(a, st)
                             : launch_cfg<MODE, WM, WN, MF, 1, PRO, EPI, 1, 1>(a, st);
     if constexpr (ragged_ok)
         return a.nsplit > 1 ? launch_cfg<MODE, WM, WN, MF, 1, PRO, EPI, 2, 0>(a, st)
                             : launch_cfg<MODE, WM, WN, MF, 1, PRO, EPI, 1, 0>(a, st);
+#endif
     return hipErrorInvalidValue;
 }
 
