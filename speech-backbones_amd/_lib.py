@@ -934,7 +934,6 @@ def clear_packed_cache():
     global _PACK_GEN
     _PACK_GEN += 1
     _PACKED.clear()
-    _PACK_PLANS.clear()
 
 
 def _packed_weight(weight, cin, cout, transposed, kind):
@@ -971,53 +970,65 @@ def _packed_conv3x3(weight, cin, cout, transposed):
     return _packed_weight(weight, cin, cout, transposed, "3x3")
 
 
-_PACK_PLANS = {}       # signature of a spec list -> device descriptor table + the blobs it fills
 _KIND_CODE = {"3x3": 0, "1x1": 1, "dn": 2, "up": 3, "dn_T": 4}
+
+
+class PackSpecs(list):
+    """[(weight, cin, cout, transposed, kind)] of one module tree, plus the batched-pack plan built for it (device descriptor table +
+    the blobs it fills).  The plan hangs off THIS list, and the list off the estimator it was built from (_train_ops._pack_specs), so
+    weights, blobs and table die with the estimator; there is no module-global table of plans."""
+    plan = None
+
+
+def _build_pack_plan(specs, dev, sig):
+    L = lib()
+    n = len(specs)
+    items = (PackItem * n)()
+    blobs = []
+    with _on(dev):
+        for k, (w, ci, co, t, kind) in enumerate(specs):
+            if kind == "3x3":
+                nb = L.gtts_conv3x3_packed_bytes(int(ci), int(co))
+            elif kind == "1x1":
+                nb = L.gtts_conv1x1_packed_bytes(int(ci), int(co))
+            else:
+                nb = L.gtts_conv_resample_packed_bytes(int(ci), int(co), 0 if kind == "dn" else 1)
+            blob = torch.empty(int(nb), dtype=torch.uint8, device=dev)
+            blobs.append(blob)
+            items[k].w, items[k].packed = w.data_ptr(), blob.data_ptr()
+            items[k].kind, items[k].cin, items[k].cout, items[k].transposed = _KIND_CODE[kind], int(ci), int(co), 1 if t else 0
+        nbytes = int(L.gtts_pack_batch_desc_bytes(n))
+        host = (ctypes.c_ubyte * nbytes)()
+        grid = ctypes.c_int(0)
+        _check(L.gtts_pack_batch_describe(items, n, ctypes.cast(host, ctypes.c_void_p), ctypes.byref(grid)), "gtts_pack_batch_describe")
+        desc = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev)
+    # (weights are referenced weakly here: the spec list is what keeps them alive)
+    return {"desc": desc, "n": n, "grid": int(grid.value), "sig": sig,
+            "entries": [((id(w), bool(t), kind), weakref.ref(w), blob) for (w, ci, co, t, kind), blob in zip(specs, blobs)]}
 
 
 def prepack(specs):
     """All weight packs of one training step in ONE launch (gtts_pack_batch).  specs: [(weight, cin, cout, transposed, kind)] with the
-    meanings of _packed_weight (cin / cout of the convolution being packed).  The blobs are allocated once per spec list and re-filled
-    in place at every call; the per-weight cache entries are stamped with the current pack generation, so the autograd Functions of
-    this step find them and nothing older survives.  Call after new_pack_generation(), on the stream the step runs on."""
+    meanings of _packed_weight (cin / cout of the convolution being packed).  With a PackSpecs list the blobs are allocated once and
+    re-filled in place at every call (a plain list gets a plan per call); the per-weight cache entries are stamped with the current pack
+    generation, so the autograd Functions of this step find them and nothing older survives.  Call after new_pack_generation(), on
+    the stream the step runs on."""
     if not specs:
         return
     L = lib()
     dev = specs[0][0].device
     sig = tuple([w.data_ptr() for w, *_ in specs])          # (cheap per-step check: the addresses the descriptor table holds)
-    plan = _PACK_PLANS.get(id(specs))
-    if plan is None or plan["sig"] != sig or plan["specs"] is not specs:
-        n = len(specs)
-        items = (PackItem * n)()
-        blobs = []
-        with _on(dev):
-            for k, (w, ci, co, t, kind) in enumerate(specs):
-                if kind == "3x3":
-                    nb = L.gtts_conv3x3_packed_bytes(int(ci), int(co))
-                elif kind == "1x1":
-                    nb = L.gtts_conv1x1_packed_bytes(int(ci), int(co))
-                else:
-                    nb = L.gtts_conv_resample_packed_bytes(int(ci), int(co), 0 if kind == "dn" else 1)
-                blob = torch.empty(int(nb), dtype=torch.uint8, device=dev)
-                blobs.append(blob)
-                items[k].w, items[k].packed = w.data_ptr(), blob.data_ptr()
-                items[k].kind, items[k].cin, items[k].cout, items[k].transposed = _KIND_CODE[kind], int(ci), int(co), 1 if t else 0
-            nbytes = int(L.gtts_pack_batch_desc_bytes(n))
-            host = (ctypes.c_ubyte * nbytes)()
-            grid = ctypes.c_int(0)
-            _check(L.gtts_pack_batch_describe(items, n, ctypes.cast(host, ctypes.c_void_p), ctypes.byref(grid)), "gtts_pack_batch_describe")
-            desc = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev)
-        # (the plan keeps the spec list alive: its id is the cache key; weights are referenced weakly through the per-weight entries)
-        plan = {"desc": desc, "n": n, "grid": int(grid.value), "sig": sig, "specs": specs,
-                "entries": [((id(w), bool(t), kind), weakref.ref(w), w, blob) for (w, ci, co, t, kind), blob in zip(specs, blobs)]}
-        if len(_PACK_PLANS) >= 8:
-            _PACK_PLANS.clear()
-        _PACK_PLANS[id(specs)] = plan
+    plan = getattr(specs, "plan", None)
+    if plan is None or plan["sig"] != sig or plan["n"] != len(specs):
+        plan = _build_pack_plan(specs, dev, sig)
+        if isinstance(specs, PackSpecs):
+            specs.plan = plan
     with _on(dev):
         _check(L.gtts_pack_batch(_ptr(plan["desc"]), plan["n"], plan["grid"], _stream()), "gtts_pack_batch")
     gen = _PACK_GEN
-    for key, ref, w, blob in plan["entries"]:
-        _PACKED[key] = (ref, w._version, gen, blob)
+    for (key, ref, blob), spec in zip(plan["entries"], specs):
+        w = spec[0]
+        _PACKED[key] = (ref if ref() is w else weakref.ref(w), w._version, gen, blob)
 
 
 def _const(device, kind, *shape):

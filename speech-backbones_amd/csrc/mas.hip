@@ -9,6 +9,7 @@
 // compares value[index][y-1] < value[index-1][y-1]; that predicate is recorded per cell during the forward
 // sweep (1 byte in caller-provided scratch), so the DP matrix itself is never written back and `value` stays
 // read-only.
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 
@@ -212,7 +213,9 @@ hipError_t launch_mas(const float *value, const float *mask, const int *t_x, con
     // one DP wave per sample (66-132 KB of LDS); if the device refuses that much dynamic LDS the column-sweep kernel below
     // (2 tx floats) computes the same path -- both restate core.pyx:9-35 cell for cell
     e = hipErrorInvalidValue;
-    if (tx <= 256) e = launch_mas_wave<4, 32>(value, mask, t_x, t_y, path, scratch, b, tx, ty, st);
+    const char *force = getenv("GTTS_MAS_KERNEL");              // "sweep": tests compare the two kernels on the same input
+    if (force && force[0] == 's') { /* fall through to the column-sweep kernel */ }
+    else if (tx <= 256) e = launch_mas_wave<4, 32>(value, mask, t_x, t_y, path, scratch, b, tx, ty, st);
     else if (tx <= 512) e = launch_mas_wave<8, 32>(value, mask, t_x, t_y, path, scratch, b, tx, ty, st);
     else if (tx <= 1024) e = launch_mas_wave<16, 16>(value, mask, t_x, t_y, path, scratch, b, tx, ty, st);
     if (e == hipSuccess) return e;

@@ -399,10 +399,12 @@ def _pack_specs(est):
     planes) and Upsample's re-indexed gradient weight pack themselves where they are used."""
     be = backend()
     cached = est.__dict__.get("_gtts_pack_specs")
-    if cached is not None:
-        return cached                                     # (the module tree is static: built once per estimator object)
-    specs = []
+    if cached is not None and all(m.weight is s[0] for m, s in zip(cached.mods, cached)):
+        return cached                                     # (the module tree is static; a Parameter that was REPLACED rebuilds the list)
+    specs = be.PackSpecs()
+    specs.mods = []
     for mod in est.modules():
+        n0 = len(specs)
         if isinstance(mod, torch.nn.ConvTranspose2d):
             ci, co = mod.in_channels, mod.out_channels
             if mod.kernel_size == (4, 4) and be.resample_supported(ci, co, 2, 2, True):
@@ -421,6 +423,7 @@ def _pack_specs(est):
                 if be.conv1x1_supported(ci, co, need_dgrad=True):
                     specs.append((mod.weight, ci, co, False, "1x1"))
                     specs.append((mod.weight, co, ci, True, "1x1"))
+        specs.mods.extend([mod] * (len(specs) - n0))
     est.__dict__["_gtts_pack_specs"] = specs
     return specs
 

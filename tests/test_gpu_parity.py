@@ -109,6 +109,29 @@ def test_mas_random_ragged_bit_exact(S, dev, b, tx, ty):
     assert float(got.sum()) == float(yl.sum())
 
 
+@pytest.mark.parametrize("b,tx,ty", [(3, 40, 25), (2, 300, 120), (2, 600, 64), (1, 1100, 700)])
+def test_mas_more_tokens_than_frames_all_paths_agree(S, dev, b, tx, ty, monkeypatch):
+    """t_x > t_y (a degenerate band: core.pyx:18 visits no cell of the early columns, the backtrack at :27-35 walks the untouched
+    values): the reference's result is still a function of the input alone, and the one-wave kernel, the column-sweep kernel, the
+    library's host twin and the oracle port all restate it cell for cell (the compiled reference too, when present)."""
+    g = torch.Generator().manual_seed(b * 77 + tx)
+    value = torch.randn(b, tx, ty, generator=g) * 4
+    xl = torch.randint(ty + 1, tx + 1, (b,), generator=g)
+    xl[0] = tx
+    yl = torch.randint(1, ty + 1, (b,), generator=g)
+    yl[0] = ty
+    mask = (O.sequence_mask(xl, tx).unsqueeze(-1) * O.sequence_mask(yl, ty).unsqueeze(1)).float()
+    want = MAS.maximum_path_port(value, mask)
+    if MAS.ref_available():
+        assert torch.equal(want, MAS.maximum_path_ref(value, mask))
+    assert torch.equal(S.mas_maximum_path(value, mask), want)                       # host twin
+    wave = S.mas_maximum_path(value.to(dev), mask.to(dev)).cpu()
+    monkeypatch.setenv("GTTS_MAS_KERNEL", "sweep")
+    sweep = S.mas_maximum_path(value.to(dev), mask.to(dev)).cpu()
+    assert torch.equal(wave, want) and torch.equal(sweep, want)
+    assert float(want.sum()) == float(yl.sum())                                    # one token per frame, whatever the band
+
+
 def test_mas_matches_compiled_reference_when_available(S, dev):
     if not MAS.ref_available():
         pytest.skip("oracle/_ref not present")

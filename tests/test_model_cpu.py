@@ -75,6 +75,30 @@ def test_sampling_on_cpu_raises_instead_of_falling_back(M):
     assert p.shape == (1, 3, 5) and float(p.sum()) == 5.0
 
 
+def test_pack_spec_list_lives_and_dies_with_the_estimator(M):
+    """The batched-pack plan of the training path hangs off the spec list, the list off the estimator (no module-global table): a
+    replaced Parameter rebuilds the list, a deleted estimator frees it (and with it the packed blobs the plan would hold)."""
+    import gc
+    import weakref
+    D = importlib.import_module("speech-backbones_amd.model.diffusion")
+    T = importlib.import_module("speech-backbones_amd.model._train_ops")
+    dec = D.Diffusion(80, 64, 1, 64, 0.05, 20.0, 1000)
+    est = dec.estimator
+    specs = T._pack_specs(est)
+    assert isinstance(specs, T.backend().PackSpecs) and len(specs) >= 2 * 24 and len(specs.mods) == len(specs)
+    assert T._pack_specs(est) is specs
+    conv = est.mid_block1.block1.block[0]
+    old = conv.weight
+    conv.weight = torch.nn.Parameter(old.detach().clone())
+    again = T._pack_specs(est)
+    assert again is not specs and all(s[0] is not old for s in again) and any(s[0] is conv.weight for s in again)
+    assert not hasattr(T.backend(), "_PACK_PLANS")
+    ref = weakref.ref(again)
+    del dec, est, specs, again, conv, old
+    gc.collect()
+    assert ref() is None
+
+
 def test_drop_in_as_top_level_model_package():
     """`PYTHONPATH=speech-backbones_amd python -c 'from model import GradTTS'` -- how inference.py imports it."""
     import os
