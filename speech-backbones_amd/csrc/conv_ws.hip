@@ -96,6 +96,9 @@ struct WsCfg {
     static constexpr int NPW = NCW == 1 ? (NKGT == 4 ? GTTS_WS_SMALL_NPW8 : 2) : ((NKGT == 4 && WM == 1 && WN == 2) ? GTTS_WS64_NPW : NCW);   // producer waves (small form: a 32-channel
                                                      // consumer tile takes 4.3k cycles per chunk, one producer wave needs 6k to stage it)
     static constexpr int NT = (NCWP + NPW) * 64; // threads per workgroup
+    // waves per SIMD the registers are budgeted for: 3 (168 registers) for the 12-wave 64-channel tile, and for the five-wave small
+    // form of the f16 + fp8 split -- two of its workgroups per CU are ten waves; at 2 waves per SIMD (256 registers) only one fits
+    static constexpr int WPS = (NT >= 768 || (NCW == 1 && NT > 256)) ? 3 : 2;
     static constexpr int MT = WM * MF * 32;      // output channels per workgroup
     static constexpr int TR = WN * NF;           // output rows per workgroup
     static constexpr int HR = TR + 2, HC = 34;   // halo tile
@@ -116,7 +119,7 @@ static inline size_t ws_smem_bytes(int npix, int nsplit, int ring, int cin, int 
 // [kg 0..3][pixel][8 channels], plane 1 the fp8 cross-term operands [g = plane * 2 + half][pixel][16 channels]; the consumers issue
 // two fp16 k-steps and one fp8 K = 64 step per tap (2/3 of the bf16x3 MFMA cycles, 1.53x its sustained rate).
 template <int WM, int WN, int MF, int NF, int PRO, int NSPLIT, typename AT, int RING>
-__global__ __launch_bounds__((WsCfg<WM, WN, MF, NF, NSPLIT == 3 ? 4 : 2>::NT), ((WsCfg<WM, WN, MF, NF, NSPLIT == 3 ? 4 : 2>::NT) >= 768 ? 3 : 2))
+__global__ __launch_bounds__((WsCfg<WM, WN, MF, NF, NSPLIT == 3 ? 4 : 2>::NT), (WsCfg<WM, WN, MF, NF, NSPLIT == 3 ? 4 : 2>::WPS))
 void conv3x3_ws_kernel(const ConvArgs a) {
     constexpr bool F8 = NSPLIT == 3;
     using C = WsCfg<WM, WN, MF, NF, F8 ? 4 : 2>;
@@ -309,7 +312,7 @@ void conv3x3_ws_kernel(const ConvArgs a) {
             constexpr int FR = TR / NBW;                             // rows (accumulators) per wave
             constexpr int NS = 3 * FR;                               // MFMA slots per tap
             constexpr int NWS = FR >= 10 ? 2 : GTTS_WS64_NWS;        // weight sets in flight (a tap is 128 FR cycles)
-            constexpr int LEAD = C::NT >= 768 ? GTTS_WS64_LEAD : GTTS_WS_LEAD;   // cycles between a fragment's ds_read and its MFMA (three waves per SIMD: 168 registers)
+            constexpr int LEAD = C::WPS >= 3 ? GTTS_WS64_LEAD : GTTS_WS_LEAD;   // cycles between a fragment's ds_read and its MFMA (three waves per SIMD: 168 registers)
             const int cbk = wave % CB, bnd = wave / CB;              // wave -> (channel block, band)
             const int fm0 = cbk * 32;
             f32x16 facc[FR];

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 S = importlib.import_module("speech-backbones_amd")
 from oracle import gradtts_oracle as O  # noqa: E402  (weights only; diagnostic)
-B, T = 16, 1024
+B, T = int(os.environ.get("TRACE_B", "16")), 1024
 dev = torch.device("cuda:0")
 sd = O.make_estimator_state(seed=0)
 prec = {"bf16x3": S.PREC_BF16X3, "f16f8": S.PREC_F16F8}[os.environ.get("TRACE_PREC", "bf16x3")]
@@ -27,14 +27,14 @@ rc = lib.gtts_debug_trace_ws(buf, 8192)
 a = np.array(buf[:], dtype=np.float64).reshape(64, 16, 8)
 sel = a[:, 0, 4] > 0
 a = a[sel]
-ncw = 4
-npw = int((a[0, 4:, 4] > 0).sum())            # producer waves that wrote a total (4, or 8 in the 64-channel tile of the f16 + fp8 form)
+ncw = int(os.environ.get("TRACE_NCW", "4"))      # consumer waves of the traced form (small-launch form: 1)
+npw = int((a[0, ncw:, 4] > 0).sum())            # producer waves that wrote a total (4, or 8 in the 64-channel tile of the f16 + fp8 form)
 print("rc", rc, "workgroups traced", a.shape[0], "(last traced launch of the call); producer waves", npw)
 c, p = a[:, :ncw], a[:, ncw:ncw + npw]
 items = c[:, :, 3].mean()
 print("consumer: items %.0f  total %.0f cycles" % (items, c[:, :, 4].mean()))
 for i, n in enumerate(["image wait", "chunk loops", "tile epilogues"]):
-    print("  %-16s %10.0f  per item %8.0f  (%4.1f%%)   per wave %s" % (n, c[:, :, i].mean(), c[:, :, i].mean() / items, 100 * c[:, :, i].mean() / c[:, :, 4].mean(), " ".join("%6.0f" % (c[:, w, i].mean() / items) for w in range(4))))
+    print("  %-16s %10.0f  per item %8.0f  (%4.1f%%)   per wave %s" % (n, c[:, :, i].mean(), c[:, :, i].mean() / items, 100 * c[:, :, i].mean() / c[:, :, 4].mean(), " ".join("%6.0f" % (c[:, w, i].mean() / items) for w in range(ncw))))
 print("producer: total %.0f cycles" % p[:, :, 4].mean())
 for i, n in enumerate(["slot wait", "staging", "request setup", "finish_tile"]):
     print("  %-16s %10.0f  per item %8.0f  (%4.1f%%)" % (n, p[:, :, i].mean(), p[:, :, i].mean() / items, 100 * p[:, :, i].mean() / p[:, :, 4].mean()))
