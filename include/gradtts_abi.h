@@ -170,7 +170,8 @@ int gtts_vc_reverse_diffusion(gtts_plan *plan, const void *packed, const float *
 
 /* ---- monotonic_align.maximum_path  monotonic_align/core.pyx:9-45 + __init__.py:8-23 ------------------- */
 /* value [b,tx,ty] fp32 (NOT modified), mask [b,tx,ty] fp32 or NULL, t_x / t_y [b] int32 device arrays,
- * path [b,tx,ty] int32 (written: 0/1), scratch >= gtts_mas_scratch_bytes(b,tx,ty) device bytes. */
+ * path [b,tx,ty] int32 (written: 0/1), scratch >= gtts_mas_scratch_bytes(b,tx,ty) device bytes.  t_x[i] > t_y[i] (an empty band in
+ * core.pyx:18) follows the reference too: its backtrack over the untouched values. */
 size_t gtts_mas_scratch_bytes(int b, int tx, int ty);
 int gtts_mas_maximum_path(const float *value, const float *mask, const int *t_x, const int *t_y, int *path,
                           void *scratch, int b, int tx, int ty, gtts_stream_t stream);

@@ -15,6 +15,27 @@
 
 namespace gtts {
 
+// t_x > t_y (more tokens than frames; nothing the alignment of tts.py:116-127 produces): the band of core.pyx:18 is empty in EVERY
+// column (lo = t_x - t_y + y > y = hi - 1), the reference's in-place `value` stays the raw value * mask, and its backtrack (:32-35) walks
+// those.  One thread restates that walk (t_y dependent loads; the read at y == 0 never reaches `path`).
+__device__ static void mas_degenerate(const float *__restrict__ val, const float *__restrict__ msk, int *__restrict__ path, size_t base,
+                                      int t_x, int t_y, int ty) {
+    int index = t_x - 1;
+    for (int y = t_y - 1; y >= 0; --y) {
+        path[base + (size_t)index * ty + y] = 1;
+        if (index != 0) {
+            bool dec = index == y;
+            if (!dec && y > 0) {
+                const size_t o1 = (size_t)index * ty + (y - 1), o0 = (size_t)(index - 1) * ty + (y - 1);
+                const float a = msk ? __fmul_rn(val[o1], msk[o1]) : val[o1];
+                const float c = msk ? __fmul_rn(val[o0], msk[o0]) : val[o0];
+                dec = a < c;
+            }
+            if (dec) index -= 1;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void mas_kernel(const float *__restrict__ value, const float *__restrict__ mask,
                                                   const int *__restrict__ t_xs, const int *__restrict__ t_ys,
                                                   int *__restrict__ path, unsigned char *__restrict__ flags, int tx,
@@ -29,6 +50,10 @@ __global__ __launch_bounds__(256) void mas_kernel(const float *__restrict__ valu
     const float *msk = mask ? mask + base : nullptr;
     unsigned char *flg = flags + base;
     float *prev = sm, *cur = sm + tx;
+    if (t_x > t_y) {
+        if (tid == 0) mas_degenerate(val, msk, path, base, t_x, t_y, ty);
+        return;
+    }
 
     for (int y = 0; y < t_y; ++y) {
         const int lo = max(0, t_x + y - t_y), hi = min(t_x, y + 1);
@@ -85,6 +110,10 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float *__restrict__
     const float *msk = mask ? mask + base : nullptr;
     unsigned short *flg = flags + (size_t)b * ty * 64;
     const int ntile = (t_y + TY - 1) / TY;
+    if (t_x > t_y) {
+        if (tid == 0) mas_degenerate(val, msk, path, base, t_x, t_y, ty);
+        return;
+    }
 
     // stage tile t into buffer t & 1: lane -> (row parity group, column), TY columns per row segment
     auto stage = [&](int t, int first_wave, int nwaves) {
