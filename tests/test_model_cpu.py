@@ -99,6 +99,26 @@ def test_pack_spec_list_lives_and_dies_with_the_estimator(M):
     assert ref() is None
 
 
+def test_plan_variant_by_batch_size(M):
+    """The drop-in estimator picks its plan by batch size in the default precision (model/diffusion.py::_variant): the persistent kernel,
+    unsplit, at B = 1 and B >= 7; the uniform-wave kernel on three sub-batch streams for B = 2..6; one plan per variant, rebuilt by
+    set_precision; the other precisions keep a single plan."""
+    D = importlib.import_module("speech-backbones_amd.model.diffusion")
+    S = importlib.import_module("speech-backbones_amd")
+    est = D.Diffusion(80, 64, 1, 64, 0.05, 20.0, 1000).estimator
+    assert [est._variant(b) for b in (None, 1, 2, 6, 7, 16, 32)] == ["main", "main", "mid", "mid", "main", "main", "main"]
+    p1, p4, p16 = est._plan(1), est._plan(4), est._plan(16)
+    assert p1 is p16 and p4 is not p1 and est._plan(6) is p4
+    assert p1.conv_ws is True and p1._nstreams == 0 and p1.cfg.precision == S.PREC_F16F8
+    assert p4.conv_ws is False and p4._nstreams == 3 and p4.cfg.precision == S.PREC_F16F8
+    est.set_precision("bf16x3")
+    assert [est._variant(b) for b in (1, 4, 16)] == ["main"] * 3
+    q = est._plan(4)
+    assert q is not p4 and q is est._plan(16) and q.cfg.precision == S.PREC_BF16X3
+    with pytest.raises(KeyError):
+        est.set_precision("fp64")
+
+
 def test_drop_in_as_top_level_model_package():
     """`PYTHONPATH=speech-backbones_amd python -c 'from model import GradTTS'` -- how inference.py imports it."""
     import os
