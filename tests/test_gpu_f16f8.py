@@ -12,6 +12,7 @@ import importlib
 import pytest
 import torch
 
+from conftest import oracle_n50
 from oracle import gradtts_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -107,11 +108,9 @@ def test_local_block_conv_on_hip_inputs(S, dev, conv_ws):
 def test_reverse_diffusion_n50_t1024_vs_oracle(S, dev, conv_ws):
     """The headline configuration's own N and T, one full and one ragged utterance (the scale-350 fixture: block inputs reach
     |x| = 450, tools/numerics_emul.py)."""
-    sd = O.make_estimator_state(seed=0)
+    sd, inp, ref = oracle_n50("scale350")
     plan = S.Plan(precision=S.PREC_F16F8, conv_ws=conv_ws)
     blob = plan.pack(sd, dev)
-    inp = O.make_inputs(2, 1024, seed=1234, ragged=True)
-    ref = O.reverse_diffusion(sd, inp["z"], inp["mask"], inp["mu"], 50)
     out = plan.reverse_diffusion(blob, inp["z"].to(dev), inp["mask"].to(dev), inp["mu"].to(dev), 50).cpu()
     assert torch.isfinite(out).all()
     assert float((out * (1 - inp["mask"])).abs().max()) == 0.0
@@ -123,13 +122,9 @@ def test_reverse_diffusion_n50_t1024_vs_oracle(S, dev, conv_ws):
 @both_convs
 def test_reverse_diffusion_n50_t1024_mel_scale_abs(S, dev, conv_ws):
     """Same N and T on the mel-scale fixture: the north star's literal 1e-3 max-abs."""
-    sd = dict(O.make_estimator_state(seed=0))
-    sd["final_conv.weight"] = sd["final_conv.weight"] * 0.1
-    sd["final_conv.bias"] = sd["final_conv.bias"] * 0.1
+    sd, inp, ref = oracle_n50("melscale")
     plan = S.Plan(precision=S.PREC_F16F8, conv_ws=conv_ws)
     blob = plan.pack(sd, dev)
-    inp = O.make_inputs(1, 1024, seed=21, temperature=150.0, ragged=False)
-    ref = O.reverse_diffusion(sd, inp["z"], inp["mask"], inp["mu"], 50)
     out = plan.reverse_diffusion(blob, inp["z"].to(dev), inp["mask"].to(dev), inp["mu"].to(dev), 50).cpu()
     err = float((out - ref).abs().max())
     print("f16f8 mel-scale N=50: max|ref| %.4g  max|err| %.3e" % (float(ref.abs().max()), err))

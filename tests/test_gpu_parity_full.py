@@ -16,6 +16,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from conftest import oracle_n50
+
 from oracle import diffvc_oracle as V
 from oracle import gradtts_oracle as O
 
@@ -44,12 +46,10 @@ def relerr(a, b):
 def test_reverse_diffusion_n50_t1024_vs_oracle(S, dev):
     """The headline configuration's own N and T: free-running 50 Euler steps on 80x1024, one full and one ragged
     utterance (Grad-TTS/model/diffusion.py:254-275).  CPU oracle: ~20 s per utterance."""
-    sd = O.make_estimator_state(seed=0)
+    sd, inp, ref = oracle_n50("scale350")                         # (shared with tests/test_gpu_f16f8.py: computed once per process)
     plan = S.Plan()
     blob = plan.pack(sd, dev)
-    inp = O.make_inputs(2, 1024, seed=1234, ragged=True)          # lengths [1024, 799]
     assert inp["lengths"].tolist() == [1024, 799]
-    ref = O.reverse_diffusion(sd, inp["z"], inp["mask"], inp["mu"], 50)
     out = plan.reverse_diffusion(blob, inp["z"].to(dev), inp["mask"].to(dev), inp["mu"].to(dev), 50).cpu()
     assert torch.isfinite(out).all()
     assert float((out * (1 - inp["mask"])).abs().max()) == 0.0
@@ -60,13 +60,9 @@ def test_reverse_diffusion_n50_t1024_vs_oracle(S, dev):
 
 def test_reverse_diffusion_n50_t1024_mel_scale_abs(S, dev):
     """Same N and T on the mel-scale fixture (sample stays |x| < 20): the north-star's literal 1e-3 max-abs."""
-    sd = dict(O.make_estimator_state(seed=0))
-    sd["final_conv.weight"] = sd["final_conv.weight"] * 0.1
-    sd["final_conv.bias"] = sd["final_conv.bias"] * 0.1
+    sd, inp, ref = oracle_n50("melscale")
     plan = S.Plan()
     blob = plan.pack(sd, dev)
-    inp = O.make_inputs(1, 1024, seed=21, temperature=150.0, ragged=False)
-    ref = O.reverse_diffusion(sd, inp["z"], inp["mask"], inp["mu"], 50)
     out = plan.reverse_diffusion(blob, inp["z"].to(dev), inp["mask"].to(dev), inp["mu"].to(dev), 50).cpu()
     print("mel-scale N=50: max|ref| %.4g  max|err| %.3e" % (float(ref.abs().max()), float((out - ref).abs().max())))
     assert 1.0 < float(ref.abs().max()) < 20
