@@ -1,4 +1,4 @@
-"""CPU emulation of candidate MFMA operand splits for the 3x3 Block convolutions (tools only; never imported by the product).
+"""CPU emulation of candidate MFMA operand splits for the 3x3 Block convolutions (test infrastructure: built on the oracle, never imported by the product; run from the repository root: python tests/numerics_emul.py).
 
 Question: which split of an fp32 contraction into low-precision MFMA passes keeps the N = 50 sampler inside the
 north-star's 1e-3 max-abs on the mel-scale fixture (tests/test_gpu_parity_full.py::test_reverse_diffusion_n50_t1024_mel_scale_abs)?

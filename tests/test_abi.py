@@ -162,17 +162,17 @@ def test_mas_cpu_twin_bit_exact():
 
 
 def test_oracle_is_test_infrastructure_only():
-    """Nothing under the package imports oracle/; bench.py touches it only inside its CPU-baseline legs (the functions whose
-    result is a `cpu_baseline` / `cpu_ms` entry), never for weights, inputs or the measured path."""
+    """Nothing under the package or under tools/ imports oracle/; bench.py touches it only inside its CPU-baseline legs (the functions
+    whose result is a `cpu_baseline` / `cpu_ms` entry), never for weights, inputs or the measured path."""
     import ast
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    pkg_dir = os.path.join(root, "speech-backbones_amd")
-    for dirpath, _, files in os.walk(pkg_dir):
-        for fn in files:
-            if fn.endswith(".py"):
-                src = open(os.path.join(dirpath, fn)).read()
-                assert "from oracle" not in src and "import oracle" not in src, os.path.join(dirpath, fn)
+    for top in ("speech-backbones_amd", "tools"):
+        for dirpath, _, files in os.walk(os.path.join(root, top)):
+            for fn in files:
+                if fn.endswith(".py"):
+                    src = open(os.path.join(dirpath, fn)).read()
+                    assert "from oracle" not in src and "import oracle" not in src, os.path.join(dirpath, fn)
     tree = ast.parse(open(os.path.join(root, "bench.py")).read())
     allowed = {"cpu_baseline", "cpu_baseline_vc", "bench_hifigan", "mas"}
 

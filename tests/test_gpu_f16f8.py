@@ -3,7 +3,7 @@
 
 The bounds are the ones the bf16x3 mode is held to (tests/test_gpu_parity*.py): 1e-4 of max|ref| per estimator call and per
 tap, 1e-4 relative / 1e-3 max-abs on the mel-scale fixture for the free-running N = 50 sampler at T = 1024 -- the north
-star's tolerance.  Expected (tools/numerics_emul.py, tools/probe/f8_probe2.hip): ~3x the bf16x3 error, i.e. ~5e-5 per call
+star's tolerance.  Expected (tests/numerics_emul.py, tools/probe/f8_probe2.hip): ~3x the bf16x3 error, i.e. ~5e-5 per call
 and ~5e-4 at N = 50.  Also: results do not depend on how utterances are batched (bit-identical), masked frames are exactly
 zero, activations beyond the fp8 operand's range degrade gracefully (finite, fp16-grade), not to NaN.
 """
@@ -107,7 +107,7 @@ def test_local_block_conv_on_hip_inputs(S, dev, conv_ws):
 @both_convs
 def test_reverse_diffusion_n50_t1024_vs_oracle(S, dev, conv_ws):
     """The headline configuration's own N and T, one full and one ragged utterance (the scale-350 fixture: block inputs reach
-    |x| = 450, tools/numerics_emul.py)."""
+    |x| = 450, tests/numerics_emul.py)."""
     sd, inp, ref = oracle_n50("scale350")
     plan = S.Plan(precision=S.PREC_F16F8, conv_ws=conv_ws)
     blob = plan.pack(sd, dev)

@@ -5,10 +5,21 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 S = importlib.import_module("speech-backbones_amd")
-from oracle import gradtts_oracle as O  # noqa: E402  (weights only; diagnostic)
 B, T = int(os.environ.get("TRACE_B", "16")), 1024
 dev = torch.device("cuda:0")
-sd = O.make_estimator_state(seed=0)
+def _fixture_state():
+    """torch.manual_seed(0) default init of the reference architecture with Rezero.g = 0.02, from the product's own module (as bench.py)."""
+    D = importlib.import_module("speech-backbones_amd.model.diffusion")
+    torch.manual_seed(0)
+    dec = D.Diffusion(80, 64, 1, 64, 0.05, 20.0, 1000)
+    sd = {k[len("estimator."):]: v.detach().clone() for k, v in dec.state_dict().items()}
+    for k in sd:
+        if k.endswith(".fn.g"):
+            sd[k].fill_(0.02)
+    return sd
+
+
+sd = _fixture_state()
 prec = {"bf16x3": S.PREC_BF16X3, "f16f8": S.PREC_F16F8}[os.environ.get("TRACE_PREC", "bf16x3")]
 plan = S.Plan(n_spks=1, streams=0, conv_ws=True, precision=prec)
 print("precision", os.environ.get("TRACE_PREC", "bf16x3"), "conv_ws", plan.conv_ws)
