@@ -11,7 +11,8 @@
  *     reference's own layouts ([B,80,T] mels, [B,1,T] masks flattened to [B,T], NCHW inside).
  *   - the CALLER owns every device buffer (inputs, outputs, packed weights, workspace); the library never
  *     allocates device memory and keeps no device pointer after a call returns.
- *   - every call enqueues on the given hipStream_t and returns without synchronising.  The sampler may fan sub-batches
+ *   - every call enqueues on the given hipStream_t and returns without synchronising (two documented exceptions, both off the
+ *     sampling path: gtts_pack_weights of a GTTS_PREC_F16F8 plan and gtts_workspace_status).  The sampler may fan sub-batches
  *     out onto side streams, but only onto streams the CALLER registered with gtts_plan_set_streams (they are forked
  *     from and joined back into the call's stream inside the call, also on error paths).
  *   - a plan is host-side metadata.  Query functions take `const gtts_plan *` and touch nothing; the enqueueing
@@ -34,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GTTS_ABI_VERSION 5
+#define GTTS_ABI_VERSION 6
 
 enum {
     GTTS_OK = 0,
@@ -43,7 +44,8 @@ enum {
     GTTS_E_CONFIG = -3,      /* unsupported model configuration                           */
     GTTS_E_HIP = -4,         /* HIP launch / runtime error (text in gtts_last_error)      */
     GTTS_E_PARAMS = -5,      /* parameter list does not match the plan's state_dict layout */
-    GTTS_E_WORKSPACE = -6    /* workspace too small                                       */
+    GTTS_E_WORKSPACE = -6,   /* workspace too small                                       */
+    GTTS_E_RANGE = -7        /* ABI 6: a value lies outside the range the plan's precision represents (GTTS_PREC_F16F8 weights) */
 };
 
 /* precision of the dense contractions (3x3 / 1x1 / transposed convs, attention products) */
@@ -57,8 +59,14 @@ enum {
                                 on the 3x3 Block convolutions: x = fp16 hi + residual; hi*hi on the fp16 MFMA, both cross terms
                                 (w * x_lo + w_lo * x, operands rounded to fp8 e4m3) in ONE fp8 MFMA per 32 channels.  Every other
                                 contraction of the plan (1x1, resampling, attention, the 2-channel first layer) stays BF16X3.
-                                Activations beyond +-1024 keep fp16-grade cross terms (the fp8 operand saturates), beyond
-                                65504 they overflow the fp16 half; conv weights must satisfy |w| < 63.  conv_ws is ignored. */
+                                RANGE CONTRACT (ABI 6, enforced): 3x3 Block-convolution weights must satisfy |w| < 63.97 (w 2^10
+                                in fp16) -- gtts_pack_weights checks every such weight on the device and returns GTTS_E_RANGE
+                                naming a layer (nothing is ever packed as inf); an activation with |x| >= 1024 keeps an
+                                fp16-grade cross term only (its fp8 operand saturates; beyond 65504 the fp16 half overflows) --
+                                the staging kernels record every such event and the maximum |x| in the first 16 bytes of the
+                                caller's workspace, read with gtts_workspace_status.
+                                cfg.conv_ws selects the kernel (persistent / uniform waves) AND which layers take the split: the
+                                64-channel layers only with conv_ws = 1.  A packed blob is valid for the plan it was packed for. */
 };
 
 typedef void *gtts_stream_t; /* hipStream_t */
@@ -126,9 +134,19 @@ int gtts_plan_set_graph(gtts_plan *plan, int on);
 /* Re-layout the estimator parameters (device fp32 pointers, in gtts_plan_param_info order) into the packed
  * blob the kernels read (bf16 hi/lo MFMA fragment order for conv weights, fp32 for the rest).
  * `freq` = the 32 (dim/2) sinusoidal frequencies exp(-k ln(1e4)/(dim/2-1)) as fp32 device values computed by
- * the host exactly as SinusoidalPosEmb does (diffusion.py:121-122). */
+ * the host exactly as SinusoidalPosEmb does (diffusion.py:121-122).
+ * GTTS_PREC_F16F8 plans (ABI 6): the packer range-checks the 3x3 Block-convolution weights on the device and this call then
+ * SYNCHRONISES `stream` to read the verdict: GTTS_E_RANGE (text names the count, max |w| and a layer) when a weight does not fit
+ * the format; the blob must then not be used -- pack the model with a GTTS_PREC_BF16X3 plan instead. */
 int gtts_pack_weights(const gtts_plan *plan, const void *const *param_ptrs, int n_params, const float *freq,
                       void *packed, gtts_stream_t stream);
+
+/* ABI 6.  Activation range record of the last gtts_estimator_forward / gtts_reverse_diffusion (or gtts_vc_*) call that used
+ * `workspace` (GTTS_PREC_F16F8 plans; zero for the other precisions): *n_events = number of staging lanes x launches that split
+ * an activation with |x| >= 1024, *max_abs = the largest |x| they saw (0 when n_events == 0).  Sticky over the step ranges of one
+ * sampling run (reset where step_begin == 0, and by every estimator call).  This query -- and gtts_pack_weights of an F16F8 plan --
+ * are the only calls of the ABI that SYNCHRONISE `stream`; do not call them inside a stream capture. */
+int gtts_workspace_status(const void *workspace, unsigned *n_events, float *max_abs, gtts_stream_t stream);
 
 /* ---- GradLogPEstimator2d.forward(x, mask, mu, t, spk)  diffusion.py:174-216 -------------------------- */
 /* x, mu, out [B,F,T]; mask [B,T]; t [B]; spk [B,spk_emb_dim] (already embedded) or NULL. */

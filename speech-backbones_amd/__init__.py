@@ -6,6 +6,6 @@ The drop-in `model` package (same class names / signatures / state_dict as Grad-
 ``inference.py`` / ``train.py`` pick it up as ``from model import GradTTS``.
 """
 from . import _lib  # noqa: F401
-from ._lib import Plan, Vocoder, Encoder, PostNetPlan, PREC_BF16, PREC_BF16_STORE, PREC_BF16X3, PREC_F16F8, euler_step, mas_maximum_path  # noqa: F401
+from ._lib import Plan, Vocoder, Encoder, PostNetPlan, PREC_BF16, PREC_BF16_STORE, PREC_BF16X3, PREC_F16F8, RangeError, euler_step, mas_maximum_path  # noqa: F401
 
-__all__ = ["Plan", "Vocoder", "Encoder", "PostNetPlan", "PREC_BF16", "PREC_BF16_STORE", "PREC_BF16X3", "PREC_F16F8", "euler_step", "mas_maximum_path"]
+__all__ = ["Plan", "Vocoder", "Encoder", "PostNetPlan", "PREC_BF16", "PREC_BF16_STORE", "PREC_BF16X3", "PREC_F16F8", "RangeError", "euler_step", "mas_maximum_path"]

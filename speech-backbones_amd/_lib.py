@@ -197,15 +197,21 @@ def lib():
         L.gtts_ubench_mfma_out_floats.restype = sz
         L.gtts_ubench_mfma.argtypes = [vp, sz, vp, i, i, ctypes.POINTER(ctypes.c_double), vp]
         L.gtts_ubench_hbm.argtypes = [vp, vp, vp, sz, i, i, ctypes.POINTER(ctypes.c_double), vp]
-        if L.gtts_abi_version() != 5:
+        L.gtts_workspace_status.argtypes = [vp, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(f), vp]
+        if L.gtts_abi_version() != 6:
             raise RuntimeError("libgradtts_gfx950.so ABI version mismatch")
         _lib = L
         return _lib
 
 
+class RangeError(RuntimeError):
+    """GTTS_E_RANGE: a value lies outside what the plan's precision represents (f16f8: a 3x3 conv weight with |w| >= 63.97)."""
+
+
 def _check(rc, what):
     if rc != 0:
-        raise RuntimeError("%s failed (%d): %s" % (what, rc, lib().gtts_last_error().decode()))
+        exc = RangeError if rc == -7 else RuntimeError
+        raise exc("%s failed (%d): %s" % (what, rc, lib().gtts_last_error().decode()))
 
 
 def _stream():
@@ -357,9 +363,25 @@ class Plan:
             self._ws[key] = ws
         return ws
 
+    def range_status(self, device=None):
+        """(events, max |x|) of the activation range record of the last estimator / sampler call (PREC_F16F8: staging lanes x
+        launches that split an activation with |x| >= 1024, which keeps fp16-grade cross terms only; always (0, 0.0) in the other
+        precisions).  Synchronises the current stream."""
+        ws = None
+        for key, w in self._ws.items():
+            if device is None or key[-1] == str(device):
+                ws = w
+        if ws is None:
+            return 0, 0.0
+        n, mx = ctypes.c_uint(0), ctypes.c_float(0.0)
+        with torch.cuda.device(ws.device):
+            _check(lib().gtts_workspace_status(_ptr(ws), ctypes.byref(n), ctypes.byref(mx), _stream()), "gtts_workspace_status")
+        return int(n.value), float(mx.value)
+
     # ---- weights
     def pack(self, state, device):
-        """state: mapping name -> tensor with the estimator-level names of the reference state_dict."""
+        """state: mapping name -> tensor with the estimator-level names of the reference state_dict.
+        PREC_F16F8: raises RangeError when a 3x3 Block-convolution weight does not fit the format (|w| >= 63.97)."""
         layout = self.param_layout()
         keep = []
         for name, shape in layout:

@@ -110,6 +110,19 @@ __device__ __forceinline__ void f8_cross_pair(float x0, float x1, _Float16 h0, _
     xq = cvt2_fp8_div<HI>(u0, u1, XS, xq);
 }
 
+// Activation range record of the f16 + fp8 split (GTTS_PREC_F16F8).  The staging code keeps the running maximum of |x| of everything
+// it splits (one v_max3_f32 per value pair); a lane that saw |x| >= 1024 -- the smallest magnitude whose fp16 residual can exceed the
+// fp8 cross-term range, i.e. from where on an element is carried at fp16 grade only -- adds one event and the maximum to the caller's
+// record when its kernel ends: {unsigned events, bit pattern of max |x|} at the start of the workspace (gtts_workspace_status).
+constexpr float F8_ACT_LIMIT = 1024.0f;
+__device__ __forceinline__ float f8_range_track(float m, float a, float b) { return fmaxf(fmaxf(m, fabsf(a)), fabsf(b)); }
+__device__ __forceinline__ void f8_range_note(unsigned *rec, float m) {
+    if (rec != nullptr && !(m < F8_ACT_LIMIT)) {       // (NaN counts)
+        atomicAdd(rec, 1u);
+        atomicMax(rec + 1, __builtin_bit_cast(unsigned, m) & 0x7fffffffu);
+    }
+}
+
 // activation load / store through a buffer descriptor (per-lane byte offset + scalar byte offset), fp32 or bf16 storage
 template <typename AT>
 __device__ __forceinline__ float ld_act(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
@@ -237,6 +250,7 @@ struct ConvArgs {
     float gn_count;         // elements per group = (cout / groups) * Hout * Wout
     int tiles_x, tiles_y;
     int stat_rows;          // EPI_STATS: partial slots per (row pair, column block) instead of per tile (set by launch_cfg)
+    unsigned *sat;          // f16 + fp8 staging: activation range record {events, bit pattern of max |x|} (f8_range_note); nullptr: none
 };
 
 // geometry of one conv configuration (compile-time in the kernel, mirrored on the host)

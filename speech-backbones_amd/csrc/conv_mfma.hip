@@ -417,6 +417,7 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
     const unsigned long long tr_t0 = tr_last;
 #endif
 
+    [[maybe_unused]] float f8_vmax = 0.f;      // f16 + fp8 split: running max |x| of everything this lane split (range record, common.h)
     // ---- transform + split + stage the activation tile of a chunk (straight-line code) into image (dh, dl)
     auto stage_act = [&](int chunk, u32x4 *dh, u32x4 *dl) {
 #pragma unroll
@@ -493,6 +494,7 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
 #pragma unroll
                 for (int i = 0; i < 8; i += 2) {
                     const _Float16 h0 = (_Float16)vv[i], h1 = (_Float16)vv[i + 1];
+                    f8_vmax = f8_range_track(f8_vmax, vv[i], vv[i + 1]);
                     fh[i] = h0;
                     fh[i + 1] = h1;
                     if (i & 2) f8_cross_pair<true>(vv[i], vv[i + 1], h0, h1, lw[i >> 2], xw[i >> 2]);
@@ -751,6 +753,7 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
     }
 #endif
 
+    if constexpr (NSPLIT == 3) f8_range_note(a.sat, f8_vmax);
     // ---------------------------------------------------------------- epilogue
     const int HWout = a.Hout * a.Wout;
     float st1[MF][4], st2[MF][4];

@@ -87,6 +87,24 @@ namespace gtts {
 #ifndef GTTS_WS_LEAD
 #define GTTS_WS_LEAD 160
 #endif
+// De-phased tile epilogues.  Persistent workgroups walk equal tiles in lock-step, so all 256 CUs reach their tile epilogue together
+// and the chip's write path (6.0-6.8 TB/s: 13-14 B/clk per CU when every CU stores, 28 at 128 CUs, 33 / 50 at 64 with dword / 16-byte
+// stores -- tools/probe/mem_probe.hip, profiles/r06_mem_probe.txt) bounds it: 10.7k cycles per 128-channel tile while the MFMAs idle.
+// With GTTS_WS_DEPHASE = P > 1 phase groups the workgroups of group g (both halves / all quarters of every XCD) start
+// g x (bytes a workgroup stores per tile) / GTTS_WS_DEPHASE_BPC cycles late: meant to leave only 1 / P of the CUs storing at any time.
+// MEASURED (round 6, profiles/r06_dephase_trace.txt): it does not hold -- the late group catches up (level 0: started 2.9k cycles
+// late, its first epilogue begins 1.1k after the early group's; the HBM-bound launch re-locks the phases) or stays 3.4k behind where
+// an epilogue lasts 9k (level 2), and per-tile epilogue time does not move (5 277 vs 5 257; 8 867-9 153 vs 9 277 cycles):
+// 153.3 vs 153.1 us on the dominant kernel, 6.52-6.56 ms per call with 0 / 2 / 4 groups.  Kept buildable, OFF.
+#ifndef GTTS_WS_DEPHASE
+#define GTTS_WS_DEPHASE 0
+#endif
+#ifndef GTTS_WS_DEPHASE_BPC
+#define GTTS_WS_DEPHASE_BPC 28
+#endif
+#ifndef GTTS_WS_DEPHASE_MIN
+#define GTTS_WS_DEPHASE_MIN 2
+#endif
 template <int WM, int WN, int MF, int NF, int NKGT = 2>
 struct WsCfg {
     static constexpr int NCW = WM * WN;          // consumer wave ROWS x COLUMNS of the statistics layout: 4, 2 (64-channel tile) or 1
@@ -185,6 +203,14 @@ void conv3x3_ws_kernel(const ConvArgs a) {
     unsigned long long tr_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long tr_entry = WT_NOW();
 #endif
+    if (GTTS_WS_DEPHASE > 1 && G >= 8 * GTTS_WS_DEPHASE && my_tiles >= GTTS_WS_DEPHASE_MIN) {
+        const int grp = (blockIdx.x >> 3) % GTTS_WS_DEPHASE;          // blockIdx % 8 is the XCD: every XCD has CUs in every group
+        if (grp != 0) {
+            const long long wait = (long long)grp * (MT * TR * 32 * AB / GTTS_WS_DEPHASE_BPC) * 2 / GTTS_WS_DEPHASE;
+            const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+            while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+        }
+    }
     if (wave < NCWP) {
         // =================================================================================== CONSUMERS
         __builtin_amdgcn_s_setprio(3);         // MFMA issue wins the per-SIMD arbitration against the producers' VALU stream
@@ -492,6 +518,13 @@ void conv3x3_ws_kernel(const ConvArgs a) {
                 WT_ADD(1, tw2, tw1);
                 WT_ADD(3, 1ull, 0ull);
                 if (!last_c) { ++cc; continue; }
+#if GTTS_WS_TRACE
+                if (tr_on) {      // [5] start of the first, [6] of the last tile epilogue since kernel entry, [7] phase group
+                    if (k == 0) tr_sum[5] = tw2 - tr_entry;
+                    tr_sum[6] = tw2 - tr_entry;
+                    tr_sum[7] = (blockIdx.x >> 3) % (GTTS_WS_DEPHASE > 1 ? GTTS_WS_DEPHASE : 1);
+                }
+#endif
                 f8_epilogue(par);
                 cc = 0;
                 ++k;
@@ -629,6 +662,7 @@ void conv3x3_ws_kernel(const ConvArgs a) {
         float m_cur[LITER][4];    // ... and of the tile being STAGED (at most one tile behind)
         int lk = 0, lc = 0, loaded = 0;      // tile ordinal / chunk of the next item to REQUEST, items requested
         int sk = 0, sc_ = 0, staged = 0, ps = 0;   // ... of the next item to STAGE, items staged, ring slot
+        [[maybe_unused]] float vmax = 0.f;   // f16 + fp8 split: running max |x| of everything this lane split (range record, common.h)
         __amdgpu_buffer_rsrc_t rs0, rs1;
         auto setup_tile = [&](const TileId &t) {
             const int iy0 = t.ty * TR - 1, ix0 = t.tx * 32 - 1;
@@ -747,6 +781,7 @@ void conv3x3_ws_kernel(const ConvArgs a) {
                                 const _Float16 h = (_Float16)v;
                                 fh[j][i] = h;
                                 if (i & 1) {        // channels (i - 1, i) of frame j -> two fp8 bytes of word i >> 2, half (i >> 1) & 1
+                                    vmax = f8_range_track(vmax, vprev[j], v);
                                     if (i & 2) f8_cross_pair<true>(vprev[j], v, fh[j][i - 1], h, lw[j][i >> 2], xw[j][i >> 2]);
                                     else { lw[j][i >> 2] = 0; xw[j][i >> 2] = 0; f8_cross_pair<false>(vprev[j], v, fh[j][i - 1], h, lw[j][i >> 2], xw[j][i >> 2]); }
                                 } else {
@@ -961,6 +996,7 @@ void conv3x3_ws_kernel(const ConvArgs a) {
         }
         lds_barrier();                                 // (F)
         if (wave == NCWP && nitems > 0) finish_tile(decode(my_tiles - 1), (my_tiles - 1) & 1);
+        if constexpr (F8) f8_range_note(a.sat, vmax);
     }
 #if GTTS_WS_TRACE
     if (tr_on && lane == 0 && (blockIdx.x >> 2) < 64) {

@@ -111,7 +111,8 @@ hipError_t launch_attn_fold(const float *ctxn, const float *wq, const float *wou
                             unsigned char *wpk, size_t wpk_bstride, float *biasb, int B, int C, hipStream_t st);
 
 // ---- pack.hip
-hipError_t launch_pack_conv(int mode, const float *w, unsigned char *dst, int cin, int cout, hipStream_t st);
+// status / tag: range record of the f16 + fp8 format (mode CONV_C3 | 32), see pack.hip; nullptr: no record
+hipError_t launch_pack_conv(int mode, const float *w, unsigned char *dst, int cin, int cout, hipStream_t st, unsigned *status = nullptr, unsigned tag = 0);
 // one descriptor per convolution of a batched pack (device-resident table; 64 bytes)
 struct PackDesc {
     const float *w;

@@ -11,6 +11,7 @@
 // read-only.
 #include <cstdlib>
 #include "common.h"
+#include <atomic>
 #include "kernels.h"
 
 namespace gtts {
@@ -227,7 +228,7 @@ static hipError_t launch_mas_wave(const float *value, const float *mask, const i
     if (!attr_done[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mas_wave_kernel<R, TY>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
+        if (e != hipSuccess) { (void)hipGetLastError(); return hipErrorNotSupported; }      // the ONE failure the caller may answer with the other kernel
         attr_done[dev] = true;
     }
     hipLaunchKernelGGL((mas_wave_kernel<R, TY>), dim3(b), dim3(256), smem, st, value, mask, t_x, t_y, path,
@@ -235,20 +236,24 @@ static hipError_t launch_mas_wave(const float *value, const float *mask, const i
     return hipGetLastError();
 }
 
+// test hook (tests/test_gpu_parity.py compares the two kernels on the same input): process-wide, results are identical either way
+static std::atomic<int> g_mas_force_sweep{0};
+extern "C" void gtts_debug_mas_force_sweep(int on) { g_mas_force_sweep.store(on ? 1 : 0, std::memory_order_relaxed); }
+
 hipError_t launch_mas(const float *value, const float *mask, const int *t_x, const int *t_y, int *path,
                       unsigned char *scratch, int b, int tx, int ty, hipStream_t st) {
     hipError_t e = hipMemsetAsync(path, 0, (size_t)b * tx * ty * sizeof(int), st);
     if (e != hipSuccess) return e;
     // one DP wave per sample (66-132 KB of LDS); if the device refuses that much dynamic LDS the column-sweep kernel below
     // (2 tx floats) computes the same path -- both restate core.pyx:9-35 cell for cell
-    e = hipErrorInvalidValue;
-    const char *force = getenv("GTTS_MAS_KERNEL");              // "sweep": tests compare the two kernels on the same input
-    if (force && force[0] == 's') { /* fall through to the column-sweep kernel */ }
+    // (the column-sweep kernel runs when the device refuses the wave kernel's dynamic LDS, for tx > 1024, or when a test asked for
+    // it through gtts_debug_mas_force_sweep; any OTHER failure of the wave kernel's launch is reported, not papered over)
+    e = hipErrorNotSupported;
+    if (g_mas_force_sweep.load(std::memory_order_relaxed)) { /* fall through to the column-sweep kernel */ }
     else if (tx <= 256) e = launch_mas_wave<4, 32>(value, mask, t_x, t_y, path, scratch, b, tx, ty, st);
     else if (tx <= 512) e = launch_mas_wave<8, 32>(value, mask, t_x, t_y, path, scratch, b, tx, ty, st);
     else if (tx <= 1024) e = launch_mas_wave<16, 16>(value, mask, t_x, t_y, path, scratch, b, tx, ty, st);
-    if (e == hipSuccess) return e;
-    (void)hipGetLastError();
+    if (e != hipErrorNotSupported) return e;
     const size_t smem = (size_t)2 * tx * sizeof(float);
     if (smem > 160 * 1024) return hipErrorInvalidValue;
     if (smem > 48 * 1024) {

@@ -13,8 +13,11 @@
 namespace gtts {
 
 // one (hi, lo) element pair t of one convolution's packed blob
+// status (nullable; the f16 + fp8 format only): {count, bit pattern of max |w|, 1 + largest offending tag} of weights whose fp16 hi part
+// w 2^S would overflow -- they are packed SATURATED (finite) and gtts_pack_weights reports GTTS_E_RANGE (plan.hip)
 __device__ __forceinline__ void pack_conv_element(const float *__restrict__ w, __bf16 *__restrict__ dst, int mode_in, int cin, int cout,
-                                                  int MT, int nst, int tps, int nchunk, int ncot, int nkg, size_t t) {
+                                                  int MT, int nst, int tps, int nchunk, int ncot, int nkg, size_t t,
+                                                  unsigned *__restrict__ status = nullptr, unsigned tag = 0) {
     const int mode = mode_in & 31;
     const bool f16f8 = (mode_in & 32) != 0;      // CONV_C3 | 32: the f16 + fp8 format of GTTS_PREC_F16F8
     // decode t -> (phase, chunk, stage, cot, tap, kg, m, i)
@@ -58,6 +61,16 @@ __device__ __forceinline__ void pack_conv_element(const float *__restrict__ w, _
         // GTTS_PREC_F16F8 (common.h): split 0 = fp16(w 2^S) in the bf16 hi plane's place; split 1 = [tap][g 0..3][cout][16 bytes] fp8:
         // g = plane * 2 + half, half = 16-channel half of the 32-channel chunk; plane 0 = q8(w), plane 1 = q8(wl 2^(S+D)),
         // wl = w - hi 2^-S.  (nkg == 4: kg * 8 + i is the channel inside the chunk.)
+        // |w| 2^S must fit fp16 (|w| < 63.97): beyond it the hi part is saturated -- never inf -- and the event recorded
+        constexpr float WMAX = 65504.0f / (float)(1 << F8_S);
+        if (!(fabsf(v) <= WMAX)) {      // (NaN counts as out of range as well)
+            if (status != nullptr) {
+                atomicAdd(status + 0, 1u);
+                atomicMax(status + 1, __builtin_bit_cast(unsigned, fabsf(v)) & 0x7fffffffu);
+                atomicMax(status + 2, tag + 1);
+            }
+            v = v != v ? 0.f : (v > 0.f ? WMAX : -WMAX);
+        }
         const _Float16 h = (_Float16)(v * (float)(1 << F8_S));
         const float wl = v - (float)h * (1.0f / (float)(1 << F8_S));
         reinterpret_cast<_Float16 *>(dst)[blk * blk_elems + (((size_t)(0 * tps + tap) * nkg + kg) * MT + m) * 8 + i] = h;
@@ -78,10 +91,10 @@ __device__ __forceinline__ void pack_conv_element(const float *__restrict__ w, _
 }
 
 __global__ void pack_conv_kernel(const float *__restrict__ w, __bf16 *__restrict__ dst, int mode, int cin, int cout,
-                                 int MT, int nst, int tps, int nchunk, int ncot, int nkg, size_t total) {
+                                 int MT, int nst, int tps, int nchunk, int ncot, int nkg, size_t total, unsigned *__restrict__ status, unsigned tag) {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;   // one thread per (hi, lo) element pair
     if (t >= total) return;
-    pack_conv_element(w, dst, mode, cin, cout, MT, nst, tps, nchunk, ncot, nkg, t);
+    pack_conv_element(w, dst, mode, cin, cout, MT, nst, tps, nchunk, ncot, nkg, t, status, tag);
 }
 
 // All convolution weights of a training step in ONE launch (blockIdx.y = weight): the packs of a step live for that step only
@@ -117,11 +130,11 @@ hipError_t launch_pack_batch(const PackDesc *descs_dev, int n, int grid_x, hipSt
 
 // mode CONV_C3 + 16 / CONV_P1 + 16: the transposed (and, 3x3, flipped) packing of a conv for its data gradient (cin, cout are
 // those of the gradient convolution, i.e. swapped with respect to the forward weight tensor)
-hipError_t launch_pack_conv(int mode, const float *w, unsigned char *dst, int cin, int cout, hipStream_t st) {
+hipError_t launch_pack_conv(int mode, const float *w, unsigned char *dst, int cin, int cout, hipStream_t st, unsigned *status, unsigned tag) {
     PackDesc d;
     pack_geometry(mode, cin, cout, d);
     hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((d.total + 255) / 256)), dim3(256), 0, st, w,
-                       reinterpret_cast<__bf16 *>(dst), mode, cin, cout, d.MT, d.nst, d.tps, d.nchunk, d.ncot, d.nkg, d.total);
+                       reinterpret_cast<__bf16 *>(dst), mode, cin, cout, d.MT, d.nst, d.tps, d.nchunk, d.ncot, d.nkg, d.total, status, tag);
     return hipGetLastError();
 }
 

@@ -104,6 +104,7 @@ struct gtts_plan {
     std::map<std::string, int> pidx;
     size_t blob_bytes;
     size_t freq_off;
+    size_t status_off;         // 256 bytes: range record of gtts_pack_weights {count, max |w| bits, 1 + parameter index} (GTTS_PREC_F16F8)
     TimeMlpDesc tmlp;
     size_t spk_w0, spk_b0, spk_w2, spk_b2;
     std::vector<Tensor> tensors;
@@ -374,6 +375,8 @@ extern "C" int gtts_plan_create(const gtts_unet_cfg *cfg, gtts_plan **out) {
     // blob: frequencies first
     p->freq_off = p->blob_bytes;
     p->blob_bytes = align_up(p->blob_bytes + (size_t)(dim / 2) * 4, 256);
+    p->status_off = p->blob_bytes;
+    p->blob_bytes += 256;
     // ---- parameters in the reference's registration order (diffusion.py:139-172)
     if (multi) {
         const int E = cfg->spk_emb_dim;
@@ -638,11 +641,27 @@ extern "C" int gtts_pack_weights(const gtts_plan *plan, const void *const *param
             case 2: HIPCHK(launch_pack_conv(CONV_DN, src, blob + d.off, d.cin, d.cout, st)); break;
             case 3: HIPCHK(launch_pack_conv(CONV_UP, src, blob + d.off, d.cin, d.cout, st)); break;
             case 4: HIPCHK(launch_pack_conv(CONV_P1, src, blob + d.off, d.cin, d.cout, st)); break;
-            case 6: HIPCHK(launch_pack_conv(CONV_C3 | 32, src, blob + d.off, d.cin, d.cout, st)); break;
+            case 6: HIPCHK(launch_pack_conv(CONV_C3 | 32, src, blob + d.off, d.cin, d.cout, st, (unsigned *)(blob + plan->status_off), (unsigned)i)); break;
             case 5:
                 HIPCHK(launch_pack_attn_kv(src, blob + d.off, d.cin, st));
                 HIPCHK(launch_copy_f32(src, (float *)(blob + d.off2), (size_t)128 * d.cin, st));   // q rows 0..127
                 break;
+        }
+    }
+    if (plan->cfg.precision == GTTS_PREC_F16F8) {
+        // Range contract of the f16 + fp8 format (include/gradtts_abi.h): a Block-convolution weight with |w| 2^S beyond the fp16
+        // range cannot be represented (it was packed saturated, never inf).  The packer counted such weights on the device; this
+        // one call of the ABI synchronises its stream to read the count, so that a checkpoint outside the range is REFUSED here
+        // instead of sampling silently at a lower grade.
+        unsigned rec[3] = {0, 0, 0};
+        HIPCHK(hipMemcpyAsync(rec, blob + plan->status_off, sizeof(rec), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (rec[0] != 0) {
+            const float mx = __builtin_bit_cast(float, rec[1]);
+            const int pi = (int)rec[2] - 1;
+            const char *nm = (pi >= 0 && pi < n_params) ? plan->params[order[pi]].name.c_str() : "?";
+            return fail(GTTS_E_RANGE, "GTTS_PREC_F16F8 needs |w| < %.2f on the 3x3 Block convolutions: %u weight(s) out of range, max |w| = %g "
+                        "(e.g. in %s); pack this model with GTTS_PREC_BF16X3", 65504.0 / (double)(1 << F8_S), rec[0], (double)mx, nm);
         }
     }
     return GTTS_OK;
@@ -740,6 +759,18 @@ extern "C" size_t gtts_workspace_bytes(const gtts_plan *plan, int B, int T) {
     return whole;
 }
 
+// The activation range record of the last estimator / sampler call that used this workspace (common.h, f8_range_note): the one
+// query of the ABI that synchronises.
+extern "C" int gtts_workspace_status(const void *workspace, unsigned *n_events, float *max_abs, gtts_stream_t stream) {
+    if (!workspace) return fail(GTTS_E_NULL, "gtts_workspace_status: null workspace");
+    unsigned rec[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(rec, workspace, sizeof(rec), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (n_events) *n_events = rec[0];
+    if (max_abs) *max_abs = __builtin_bit_cast(float, rec[1]);
+    return GTTS_OK;
+}
+
 extern "C" int gtts_plan_num_tensors(const gtts_plan *plan) { return plan ? (int)plan->tensors.size() : 0; }
 
 extern "C" int gtts_vc_tensor_info(const gtts_plan *plan, int i, int B, int T, int T_ref, const char **name, size_t *offset,
@@ -775,6 +806,7 @@ struct RunCtx {
     const float *tb_row;   // tb rows of this call
     int tb_bstride;        // floats between samples' rows (0: one row shared by the batch)
     hipStream_t st;
+    unsigned *sat = nullptr;   // activation range record of the call (first 16 bytes of the caller's workspace; gtts_workspace_status)
     // DiffVC extras
     const float *ref_mask = nullptr;
     int Tr = 0;
@@ -847,6 +879,7 @@ static int run_ops(const RunCtx &c) {
                 a.f16f8 = p->cfg.precision == GTTS_PREC_F16F8 ? 1 : 0;
                 a.use_ws = p->cfg.conv_ws;
                 a.act_bf16 = abf;
+                a.sat = c.sat;
                 if (o.epi == EPI_STATS && o.gn_op >= 0 && !o.use_ref) {          // GroupNorm finalize rides in the epilogue
                     const Op &gn = p->ops[o.gn_op];
                     a.ticket = (unsigned *)tptr(c, p->t_ticket);
@@ -968,6 +1001,8 @@ extern "C" int gtts_estimator_forward(gtts_plan *plan, const void *packed, const
     const unsigned char *blob = (const unsigned char *)packed;
     RunCtx c{p, blob, (unsigned char *)workspace, mask, B, T, nullptr, 0, st};
     const int F = p->cfg.n_feats;
+    c.sat = (unsigned *)workspace;
+    HIPCHK(hipMemsetAsync(workspace, 0, 16, st));                             // activation range record of this call (gtts_workspace_status)
     HIPCHK(hipMemsetAsync(tptr(c, p->t_ticket), 0, (size_t)B * 4, st));      // tickets of the fused GroupNorm finalize
     float *s = nullptr;
     if (multi) {
@@ -1026,6 +1061,7 @@ static int enqueue_reverse_diffusion(gtts_plan *p, const void *packed, const flo
     HIPCHK(hipGetLastError());
     { ProfScope ps_(p, st, (int)p->ops.size() + XOP_TIME); HIPCHK(launch_time_mlp(tvals, (const float *)(blob + p->freq_off), p->cfg.pe_scale, blob, p->tmlp, tb, N, st)); }
     if (step_begin == 0) { ProfScope ps_(p, st, (int)p->ops.size() + XOP_MULMASK); HIPCHK(launch_mul_mask(z, mask, out, B, F, T, st)); }   // xt = z * mask  (diffusion.py:257)
+    if (step_begin == 0) HIPCHK(hipMemsetAsync(workspace, 0, 16, st));      // activation range record: sticky over the step ranges of one sampling run
 
     struct Half { RunCtx c; int b0; float *s; };
     Half hv[MAX_SUB];
@@ -1036,6 +1072,7 @@ static int enqueue_reverse_diffusion(gtts_plan *p, const void *packed, const flo
         const int bn = base + (h < rem ? 1 : 0);
         hipStream_t hs = nhalf > 1 ? p->sub[h] : st;
         hv[h].c = RunCtx{p, blob, (unsigned char *)workspace + (size_t)h * ws_half, mask + (size_t)b0 * T, bn, T, nullptr, 0, hs};
+        hv[h].c.sat = (unsigned *)workspace;         // one record per call: every sub-batch adds to the first slice's
         hv[h].b0 = b0;
         hv[h].s = nullptr;
     }
@@ -1193,6 +1230,8 @@ extern "C" int gtts_vc_estimator_forward(gtts_plan *plan, const void *packed, co
     RunCtx cx{p, blob, (unsigned char *)workspace, x_mask, B, T, nullptr, 0, st};
     cx.ref_mask = ref_mask; cx.Tr = T_ref; cx.in_x = x; cx.in_mean = mean; cx.in_c = c;
     const int F = p->cfg.n_feats;
+    cx.sat = (unsigned *)workspace;
+    HIPCHK(hipMemsetAsync(workspace, 0, 16, st));
     HIPCHK(hipMemsetAsync(tptr(cx, p->t_ticket), 0, (size_t)B * 4, st));
     float *tb = tptr(cx, p->t_tb);
     { ProfScope ps_(p, st, (int)p->ops.size() + XOP_TIME); HIPCHK(launch_time_mlp(t, (const float *)(blob + p->freq_off), p->cfg.pe_scale, blob, p->tmlp, tb, B, st)); }
@@ -1239,6 +1278,8 @@ extern "C" int gtts_vc_reverse_diffusion(gtts_plan *plan, const void *packed, co
     RunCtx cx{p, blob, (unsigned char *)workspace, mask, B, T, nullptr, 0, st};
     cx.ref_mask = ref_mask; cx.Tr = T_ref; cx.in_mean = mean; cx.in_c = c; cx.in_x = out;
     const int F = cf.n_feats, N = n_timesteps;
+    cx.sat = (unsigned *)workspace;
+    if (step_begin == 0) HIPCHK(hipMemsetAsync(workspace, 0, 16, st));
     HIPCHK(hipMemsetAsync(tptr(cx, p->t_ticket), 0, (size_t)B * 4, st));
     // step times t_i = 1 - i*h (left endpoint, diffusion.py:170) -> fp32 `time` tensor values, all rows in one launch
     float *tb = tptr(cx, p->t_tb);

@@ -76,6 +76,16 @@ def max_over_ranks(value, device):
     return float(t.item())
 
 
+def gather_floats(value, device):
+    """[value of rank 0, value of rank 1, ...] on every rank (per-rank timings in bench.py's line)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return [float(value)]
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    outs = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, mine)
+    return [float(t.item()) for t in outs]
+
+
 def gather_outputs(local_out, dst=0):
     """Optional: collect per-rank output mels on rank `dst` (not part of any timed region)."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):

@@ -192,7 +192,14 @@ class GradLogPEstimator2d(BaseModule):
     def set_precision(self, precision):
         """'f16f8' (default; fp32-grade: ~5e-5 of max|ref| per estimator call, 4e-4 max-abs on mel-scale data after 50 Euler steps),
         'bf16x3' (fp32-grade, ~2e-5 per call, every contraction as three bf16 MFMA passes), 'bf16' (single bf16 MFMA, fp32
-        activations) or 'bf16_store' (BASELINE config 3 as written: bf16 MFMA and bf16 activation storage)."""
+        activations) or 'bf16_store' (BASELINE config 3 as written: bf16 MFMA and bf16 activation storage).
+
+        Batch-size buckets (f16f8 only).  A Plan's results never depend on how utterances are batched (bit-identical).  This MODULE
+        however picks the plan by batch size (_variant): B = 1 and B >= 7 run the persistent kernel with the 64-channel layers in
+        f16 + fp8, B = 2...6 the uniform-wave kernel with those layers in bf16x3 (faster there).  The same utterance sampled alone
+        and inside a batch of four therefore differs by fp32-grade rounding (<= 1e-4 of max|x| after 50 steps, tested), not by
+        zero.  Call set_precision('bf16x3'), or pin one bucket with pin_variant('main'), where bit-equality across batch sizes
+        matters more than the B = 2...6 speed."""
         be = backend()
         self._precision = {"bf16x3": be.PREC_BF16X3, "bf16": be.PREC_BF16, "bf16_store": be.PREC_BF16_STORE, "f16f8": be.PREC_F16F8}[precision]
         self._hip_plan = None
@@ -214,7 +221,15 @@ class GradLogPEstimator2d(BaseModule):
         on one box, ms per U-Net call at B = 4: 2.45 against 2.62; B = 8: 3.72 against 3.68; B = 1: 1.48 against 1.41)."""
         be = backend()
         prec = be.PREC_F16F8 if self._precision is None else self._precision
+        if getattr(self, "_pinned_variant", None) is not None:
+            return self._pinned_variant
         return "mid" if (prec == be.PREC_F16F8 and batch is not None and 2 <= int(batch) <= 6) else "main"
+
+    def pin_variant(self, variant=None):
+        """'main' / 'mid': always take that plan whatever the batch size (results then bit-identical across batch sizes); None: by batch."""
+        if variant not in (None, "main", "mid"):
+            raise ValueError("variant must be None, 'main' or 'mid'")
+        self._pinned_variant = variant
 
     def _plan(self, batch=None):
         if tuple(self.dim_mults) != (1, 2, 4) or self.groups != 8:
@@ -248,8 +263,33 @@ class GradLogPEstimator2d(BaseModule):
             self._hip_blob = {}
             self._hip_key = key
         if var not in self._hip_blob:
-            self._hip_blob[var] = plan.pack({n: p for n, p in params}, device)
+            try:
+                self._hip_blob[var] = plan.pack({n: p for n, p in params}, device)
+            except backend().RangeError as e:
+                # the default precision has a weight range (|w| < 63.97 on the 3x3 Block convolutions, include/gradtts_abi.h); the
+                # reference's fp32 path has none.  An out-of-range checkpoint is never sampled at a lower grade silently: the
+                # module switches itself to bf16x3 (fp32-grade, no range limits, ~8 % slower) and says so.  An explicit
+                # set_precision('f16f8') is a request, not a default: then the error is the caller's to see.
+                if self._precision is not None:
+                    raise
+                import warnings
+                warnings.warn("GradLogPEstimator2d: %s -- sampling with precision 'bf16x3' instead" % e, RuntimeWarning, stacklevel=3)
+                self._precision = backend().PREC_BF16X3
+                self._hip_plan = None
+                self.invalidate_packed()
+                return self._packed(device, batch)
         return self._hip_blob[var]
+
+    def range_status(self):
+        """(events, max |x|) of the last sampling call's activation range record (see Plan.range_status): non-zero events mean
+        some activations were beyond the f16f8 cross-term range (|x| >= 1024) and were carried at fp16 grade.  Synchronises."""
+        if not self._hip_plan:
+            return 0, 0.0
+        ev, mx = 0, 0.0
+        for plan in self._hip_plan.values():
+            e, m_ = plan.range_status()
+            ev, mx = ev + e, max(mx, m_)
+        return ev, mx
 
     # ---- forward ------------------------------------------------------------------------------------
     def forward(self, x, mask, mu, t, spk=None):
@@ -260,8 +300,9 @@ class GradLogPEstimator2d(BaseModule):
                                "(there is no CPU fallback)" % x.device)
         if self.n_spks > 1 and spk is None:
             raise RuntimeError("multi-speaker estimator needs spk")
+        blob = self._packed(x.device, x.shape[0])       # (first: an out-of-range checkpoint switches the module's precision here)
         plan = self._plan(x.shape[0])
-        return plan.estimator_forward(self._packed(x.device, x.shape[0]), x, mask, mu, t, spk if self.n_spks > 1 else None)
+        return plan.estimator_forward(blob, x, mask, mu, t, spk if self.n_spks > 1 else None)
 
 
 def get_noise(t, beta_init, beta_term, cumulative=False):
@@ -310,8 +351,8 @@ class Diffusion(BaseModule):
                                "(there is no CPU fallback)" % z.device)
         est = self.estimator
         est._beta_range = (float(self.beta_min), float(self.beta_max))
+        blob = est._packed(z.device, z.shape[0])         # (first: an out-of-range checkpoint switches the module's precision here)
         plan = est._plan(z.shape[0])
-        blob = est._packed(z.device, z.shape[0])
         spk_in = spk if est.n_spks > 1 else None
         if not stoc:
             return plan.reverse_diffusion(blob, z, mask, mu, n_timesteps, spk_in)

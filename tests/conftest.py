@@ -36,7 +36,7 @@ _ORACLE_N50 = {}
 def oracle_n50(fixture):
     """(state dict, inputs, CPU-oracle result) of the free-running N = 50, T = 1024 sampler on one of the two fixtures the GPU parity
     tests of both fp32-grade precisions share -- 'scale350': one full + one ragged utterance; 'melscale': final_conv scaled by 0.1 so
-    the sample stays |x| < 20 (the north star's literal 1e-3 max-abs).  The oracle needs 1-3 minutes of host time per fixture, so
+    the sample stays |x| < 20 (the north star's literal 1e-3 max-abs); 'melscale_attn': the same with Rezero.g = 0.15 (attention on).  The oracle needs 1-3 minutes of host time per fixture, so
     its result is computed once per pytest process; callers must not modify what they get."""
     from oracle import gradtts_oracle as O
     if fixture not in _ORACLE_N50:
@@ -44,6 +44,13 @@ def oracle_n50(fixture):
         if fixture == "scale350":
             inp = O.make_inputs(2, 1024, seed=1234, ragged=True)          # lengths [1024, 799]
         elif fixture == "melscale":
+            sd["final_conv.weight"] = sd["final_conv.weight"] * 0.1
+            sd["final_conv.bias"] = sd["final_conv.bias"] * 0.1
+            inp = O.make_inputs(1, 1024, seed=21, temperature=150.0, ragged=False)
+        elif fixture == "melscale_attn":
+            # the harder fixture: linear attention materially ON (Rezero.g = 0.15 instead of 0.02: the attention branch is
+            # ~15 % of every residual it joins, at all six attention blocks), otherwise the mel-scale fixture
+            sd = dict(O.make_estimator_state(seed=0, rezero_g=0.15))
             sd["final_conv.weight"] = sd["final_conv.weight"] * 0.1
             sd["final_conv.bias"] = sd["final_conv.bias"] * 0.1
             inp = O.make_inputs(1, 1024, seed=21, temperature=150.0, ragged=False)

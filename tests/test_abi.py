@@ -106,7 +106,7 @@ def test_abi_contract_surface():
     compiled into the product library (no GTTS_SKIP_OPS / trace entry points)."""
     S = pkg()
     L = S._lib.lib()
-    assert L.gtts_abi_version() == 5
+    assert L.gtts_abi_version() == 6
     p = S.Plan(streams=0)
     assert L.gtts_plan_set_streams(p._h, None, 0) == 0
     assert L.gtts_plan_set_streams(p._h, None, 3) != 0            # null stream array
@@ -125,7 +125,7 @@ def test_abi_contract_surface():
     out = subprocess.check_output(["nm", "-D", "--defined-only", S._lib.LIB_PATH]).decode()
     assert "gtts_debug_trace" not in out
     blob = open(S._lib.LIB_PATH, "rb").read()
-    assert b"GTTS_SKIP_OPS" not in blob and b"GTTS_STREAMS" not in blob
+    assert b"GTTS_SKIP_OPS" not in blob and b"GTTS_STREAMS" not in blob and b"GTTS_MAS_KERNEL" not in blob
     # gtts_bcast_weights validates its arguments before touching RCCL
     assert L.gtts_bcast_weights(None, 0, 0, None, None) == S._lib.lib().gtts_bcast_weights(None, 0, 0, None, None) != 0
 

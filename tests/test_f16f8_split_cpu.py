@@ -72,3 +72,35 @@ def test_saturated_operands_degrade_to_fp16_grade_not_nan():
     e8, e_hi = rel(out, ref), rel(f16(w) @ f16(x), ref)
     print("saturating inputs: f16f8 %.2e  fp16 hi*hi alone %.2e" % (e8, e_hi))
     assert e8 <= e_hi * 1.05 and e8 < 2e-3
+
+
+def test_weight_range_rule_of_the_packer():
+    """pack.hip's range check restated (round-5 review 3a): fp16(w 2^S) is finite exactly for |w| <= 65504 / 2^S = 63.97; beyond it the
+    packer SATURATES the hi part (never inf) and counts the weight, and gtts_pack_weights turns a non-zero count into GTTS_E_RANGE."""
+    wmax = 65504.0 / 2.0 ** S
+    inside = torch.tensor([0.0, 1.0, -63.9, wmax, -wmax])
+    # (fp16 rounds to nearest: values up to 65519.99 still round DOWN to 65504 -- the packer's bound is the representable maximum itself,
+    # so everything it accepts is exactly in range and everything above is refused, including the few that would round down)
+    assert torch.isfinite((inside * 2.0 ** S).to(torch.float16)).all()
+    outside = torch.tensor([64.0, -70.0, 1e4, float("inf")])
+    assert not (outside.abs() <= wmax).any()
+    assert torch.isinf((torch.tensor([64.0, -70.0, 1e4]) * 2.0 ** S).to(torch.float16)).all()       # what the old packer wrote
+    sat = outside.clamp(-wmax, wmax)
+    assert torch.isfinite((sat * 2.0 ** S).to(torch.float16)).all()                                   # what the packer writes now
+    # the static side: the device check and the error path exist where the header says they do
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pack = open(os.path.join(root, "speech-backbones_amd", "csrc", "pack.hip")).read()
+    plan = open(os.path.join(root, "speech-backbones_amd", "csrc", "plan.hip")).read()
+    hdr = open(os.path.join(root, "include", "gradtts_abi.h")).read()
+    assert "WMAX = 65504.0f / (float)(1 << F8_S)" in pack and "atomicAdd(status + 0, 1u)" in pack
+    assert "return fail(GTTS_E_RANGE" in plan and "hipStreamSynchronize(st)" in plan
+    assert "GTTS_E_RANGE = -7" in hdr and "gtts_workspace_status" in hdr
+
+
+def test_activation_range_threshold():
+    """common.h F8_ACT_LIMIT = 1024: the smallest |x| whose fp16 residual can leave the fp8 operand's range (|x_l| 2^S > 448)."""
+    x = torch.linspace(512.0, 1023.99, 20001, dtype=torch.float64)
+    assert float(((x - f16(x)).abs() * 2.0 ** S).max()) <= 448.0
+    x = torch.linspace(1024.0, 2047.0, 20001, dtype=torch.float64)
+    assert float(((x - f16(x)).abs() * 2.0 ** S).max()) > 448.0

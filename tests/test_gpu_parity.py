@@ -57,7 +57,7 @@ both_convs = pytest.mark.parametrize("conv_ws", [False, True], ids=["conv_mfma",
 
 # ------------------------------------------------------------------------------------------------ library
 def test_native_library_is_loaded(S):
-    assert S._lib.lib().gtts_abi_version() == 5
+    assert S._lib.lib().gtts_abi_version() == 6
     import os
     assert os.path.exists(S._lib.LIB_PATH)
 
@@ -126,8 +126,11 @@ def test_mas_more_tokens_than_frames_all_paths_agree(S, dev, b, tx, ty, monkeypa
         assert torch.equal(want, MAS.maximum_path_ref(value, mask))
     assert torch.equal(S.mas_maximum_path(value, mask), want)                       # host twin
     wave = S.mas_maximum_path(value.to(dev), mask.to(dev)).cpu()
-    monkeypatch.setenv("GTTS_MAS_KERNEL", "sweep")
-    sweep = S.mas_maximum_path(value.to(dev), mask.to(dev)).cpu()
+    S._lib.lib().gtts_debug_mas_force_sweep(1)            # the column-sweep kernel on the same input (debug hook of the library)
+    try:
+        sweep = S.mas_maximum_path(value.to(dev), mask.to(dev)).cpu()
+    finally:
+        S._lib.lib().gtts_debug_mas_force_sweep(0)
     assert torch.equal(wave, want) and torch.equal(sweep, want)
     assert float(want.sum()) == float(yl.sum())                                    # one token per frame, whatever the band
 
