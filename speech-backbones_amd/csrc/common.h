@@ -292,7 +292,7 @@ hipError_t launch_conv(int mode, const ConvArgs &a, hipStream_t st);
 #endif
 bool conv_ws_eligible(int mode, int c0, int c1, int cout, int pro, int epi, int nsplit, int f16f8 = 0);
 int conv_ws_nparts(int cout, int Hout, int Wout);      // GroupNorm partial slots per sample it writes (one per 32-frame x 5-row block)
-bool conv_ws_small(int cout, int groups, int Hout, int Wout, int B);   // the launch takes the three-wave workgroup form (same arithmetic)
+bool conv_ws_small(int cout, int groups, int Hout, int Wout, int B, int f16f8 = 0);   // the launch takes the three-wave workgroup form (same arithmetic)
 hipError_t launch_conv_ws(const ConvArgs &a, hipStream_t st);
 // conv_up.hip: Upsample with the four output phases computed from one staged tile (fp32 storage, bf16x3)
 bool conv_up4_eligible(const ConvArgs &a);

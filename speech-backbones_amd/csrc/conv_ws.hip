@@ -127,10 +127,12 @@ struct WsCfg {
 };
 
 // nsplit planes (1: hi; 2: hi + lo, or fp16 hi + fp8 cross-term operands) of nkg 8-channel groups per ring slot
-static inline size_t ws_smem_bytes(int npix, int nsplit, int ring, int cin, int pro, int mt, int mf, int ncw, int nkg = 2) {
+// wq16: 16-byte units of the weight ring (the f16 + fp8 64-channel tile keeps two (chunk, column stage) weight blocks in LDS)
+constexpr int WS64_WST16 = 3 * 64 * 2 * 4;      // one block: [split][tap = ky][kg / g][64 couts] x 16 B = 24 KB
+static inline size_t ws_smem_bytes(int npix, int nsplit, int ring, int cin, int pro, int mt, int mf, int ncw, int nkg = 2, int wq16 = 0) {
     const size_t cpad = (size_t)((cin + 31) / 32) * 32;
-    return (size_t)ring * nsplit * nkg * npix * 16 + (pro == PRO_GN ? (size_t)2 * 3 * cpad * 4 : 0) + (size_t)2 * ncw * mf * 8 * 4 +
-           (size_t)2 * mt * 4;
+    return (size_t)ring * nsplit * nkg * npix * 16 + (size_t)wq16 * 16 + (pro == PRO_GN ? (size_t)2 * 3 * cpad * 4 : 0) +
+           (size_t)2 * ncw * mf * 8 * 4 + (size_t)2 * mt * 4;
 }
 
 // NSPLIT == 3: the f16 + fp8 split of GTTS_PREC_F16F8 (common.h) on 32-channel chunks: plane 0 of an image holds fp16 hi values
@@ -156,10 +158,19 @@ void conv3x3_ws_kernel(const ConvArgs a) {
     const int WBLK16 = 3 * MTP * 2 * NKG;
     static_assert(PRO == PRO_MASK || PRO == PRO_GN, "Block prologues only");
 
+    // W64: the 12-wave 64-channel tile of the f16 + fp8 form.  Its weights do NOT come through the vector L1 tap by tap: the CU's L1
+    // returns loads in order, and behind the producers' HBM-miss halo loads an L2-hit fragment load waits ~1000-1500 cycles at 32 KB in
+    // flight, ~3000 at this tile's 52 KB (tools/probe/mem_probe.hip; round 5: chunk loop 10.25k cycles for 5.76k of MFMA issue, 7.05k
+    // without weight reloads).  Instead every consumer wave streams its block's A fragments of one (chunk, COLUMN stage) -- the three taps
+    // (ky = 0..2) of one kx -- into 12 KB of LDS of its own with LDS-DMA (buffer_load ... lds: no registers, a whole stage = 1920 MFMA
+    // cycles ahead of their use) and reads them from there; see the consumer loop.  Column stages also let a B fragment serve three taps.
+    constexpr bool W64 = F8 && C::NCWP != C::NCW;
+    constexpr int WQ16 = W64 ? 2 * WS64_WST16 : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4 *s_img = reinterpret_cast<u32x4 *>(smem);                      // [RING][split][kg][NPIX]
+    [[maybe_unused]] u32x4 *s_wq = s_img + RING * IMG16;                 // W64: [4 consumer waves][12 pieces][64 lanes] A fragments
     const int cpad = a.nchunk * CH;
-    float *s_par = reinterpret_cast<float *>(s_img + RING * IMG16);      // PRO_GN: [2 (tile parity)][3][cpad] scale, shift, time bias
+    float *s_par = reinterpret_cast<float *>(s_img + RING * IMG16 + WQ16);   // PRO_GN: [2 (tile parity)][3][cpad] scale, shift, time bias
     float *s_red = s_par + (PRO == PRO_GN ? 2 * 3 * cpad : 0);           // [2 (tile parity)][NCW waves][MF][4 octets][2]
     float *s_epi = s_red + 2 * NCW * MF * 8;                             // [2 (tile parity)][MT] bias
 
@@ -318,6 +329,12 @@ void conv3x3_ws_kernel(const ConvArgs a) {
                     }
                 }
         };
+        if constexpr (W64) {
+            // the first (chunk 0, column stage 0) block of the weight ring, landed before anybody passes the prologue barrier
+            // one cout tile (cout == MT == 64): the bias is the same for every tile -- written once, into both parities (a load per tile
+            // would put an s_waitcnt vmcnt(0) behind the previous epilogue's stores at every tile start)
+            for (int c = tid; c < 2 * MT; c += NCT) s_epi[c] = a.bias[c % MT];
+        }
         lds_barrier();                                              // (P) prologue barrier: s_par of tile 0 is written
         int k = 0, cc = 0, slot = 0;
         if constexpr (F8) {
@@ -430,6 +447,148 @@ void conv3x3_ws_kernel(const ConvArgs a) {
                     }
                 }
             };
+            if constexpr (W64) {
+                // ------------------------------------------------------ 64-channel tile: weights from a private LDS ring, column stages
+                // An item is three COLUMN stages j = kx = 0..2 of two sweeps each; one workgroup barrier per item (the image hand-over),
+                // nothing else between waves.  Every consumer wave keeps ITS 32-channel block's weights of one (chunk, kx) -- twelve
+                // A fragments of 1 KB: (ky, k-step) x 6 for the fp16 plane, (ky, half) x 6 for the fp8 plane -- in 12 KB of LDS of its own and
+                // refills each half BEHIND its own reads: once the six fp16 fragments of stage s are in registers (their first MFMAs
+                // have issued) the wave requests the fp16 fragments of stage s + 1 into the same 6 KB by LDS-DMA, likewise the fp8 half in
+                // the fp8 sweep -- a whole stage (1920 MFMA cycles) ahead of their use, no registers, no other wave involved (the two
+                // bands of a block each fetch their copy: L2 hits).  s_waitcnt vmcnt(6) before a sweep's fragment reads = "everything but
+                // the six pieces requested last has landed" (loads return in order).  At a tile's end the two pending refills are
+                // drained with vmcnt(0) BEFORE the epilogue's 80 stores enter the queue, and the first stage of the next tile skips its
+                // two waits (a counted wait would otherwise sit behind those stores).
+                // (History, same box: weights as per-tap register loads through the L1 303 / 286 us per level-0 launch (GroupNorm / mask
+                // prologue); one shared two-block ring with all twelve waves in three barriers per item 303 / 286 -- consumers and producers
+                // then wait for each other's slowest third; the shared ring with a consumer-only arrival counter 279 / 260.)
+                // Sweeps: input rows R = 0..6 of the wave's band, one B fragment (pair) per row fetched two rows ahead and used by every
+                // (output row r = R - ky, ky) pair: 84 + 36 fragment reads per item and wave instead of 180 + 36 weight loads.
+                // Order per accumulator (every band, every batch size -- the small-launch form does not take 64-channel layers in
+                // f16 + fp8): chunk, kx; then ky 0..2: k-step 0, k-step 1; then ky 0..2: fp8.
+                typedef __attribute__((address_space(3))) void *lds_vp;
+                u32x4 *wq = s_wq + wave * (WS64_WST16 / 2);            // this wave's 12 KB: pieces 0..5 fp16 (ky * 2 + k-step), 6..11 fp8 (ky * 2 + half)
+                const int src16 = (kg_l * 64 + fm0 + l31) * 16;       // lane's byte offset inside a (tap, kg pair) segment of the packed fp16 plane ...
+                const int src8 = ((3 * NKG + kg_l * 2) * 64 + fm0 + l31) * 16;   // ... and of the fp8 plane (g = kg_l * 2 + half)
+                auto dma16 = [&](int chunk, int stage) {              // fp16 A fragments of (chunk, kx = stage): piece = ky * 2 + k-step
+                    const int so = (chunk * 3 + stage) * (WS64_WST16 * 16);
+#pragma unroll
+                    for (int p = 0; p < 6; ++p)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_vp)(wq + p * 64), 16, src16, so + (((p >> 1) * NKG + (p & 1) * 2) * 64) * 16, 0, 0);
+                };
+                auto dma8 = [&](int chunk, int stage) {               // fp8 A fragments: piece = 6 + ky * 2 + half
+                    const int so = (chunk * 3 + stage) * (WS64_WST16 * 16);
+#pragma unroll
+                    for (int p = 0; p < 6; ++p)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_vp)(wq + (6 + p) * 64), 16, src8, so + (((p >> 1) * NKG + (p & 1)) * 64) * 16, 0, 0);
+                };
+                if (nitems > 0) { dma16(0, 0); dma8(0, 0); }
+                if (GTTS_WS_EXP == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (ablation: the ring is filled once)
+                for (int i = 0; i < nitems; ++i) {
+                    const int par = k & 1;
+                    const u32x4 *xh_p = s_img + slot * IMG16 + xl0;                                  // fp16 plane, k-step 0 (k-step 1: + 2 NPIX)
+                    const u32x4 *x8_p = s_img + slot * IMG16 + PLANE16 + xl0 + kg_l * NPIX;          // fp8 plane: g = 2 kg_l (second half: + NPIX)
+                    slot = slot + 1 == RING ? 0 : slot + 1;
+                    const bool last_c = cc + 1 == nchunk;
+                    [[maybe_unused]] const unsigned long long tw0 = WT_NOW();
+                    lds_barrier();                  // image of item i is complete; everybody is done with item i - 1
+                    [[maybe_unused]] const unsigned long long tw1 = WT_NOW();
+                    WT_ADD(0, tw1, tw0);
+                    if (cc == 0) {
+#pragma unroll
+                        for (int r = 0; r < FR; ++r)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) facc[r][e] = 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const bool fresh = i == 0 ? false : (cc == 0 && j == 0);     // first stage after an epilogue: both halves landed before it
+                        const int nch = j == 2 ? (last_c ? 0 : cc + 1) : cc, nst = j == 2 ? 0 : j + 1;      // the next stage (after the last item: block 0 again, never read)
+                        // ---- f16 sweep
+                        [[maybe_unused]] const unsigned long long tv0 = WT_NOW();
+                        if (!fresh && GTTS_WS_EXP != 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                        WT_ADD(7, WT_NOW(), tv0);
+                        f16x8 wa[3], wb[3];
+#pragma unroll
+                        for (int st = 0; st < 3; ++st) {
+                            wa[st] = __builtin_bit_cast(f16x8, wq[(st * 2) * 64 + lane]);
+                            wb[st] = __builtin_bit_cast(f16x8, wq[(st * 2 + 1) * 64 + lane]);
+                        }
+                        f16x8 fa[FR + 2], fb[FR + 2];
+                        auto fetch16 = [&](int R) {
+                            fa[R] = __builtin_bit_cast(f16x8, xh_p[R * HC + j]);
+                            fb[R] = __builtin_bit_cast(f16x8, xh_p[2 * NPIX + R * HC + j]);
+                        };
+                        fetch16(0);
+                        fetch16(1);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int R = 0; R < FR + 2; ++R) {
+                            if (R + 2 < FR + 2) fetch16(R + 2);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int st = 0; st < 3; ++st)
+                                if (R - st >= 0 && R - st < FR) facc[R - st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[st], fa[R], facc[R - st], 0, 0, 0);
+#pragma unroll
+                            for (int st = 0; st < 3; ++st)
+                                if (R - st >= 0 && R - st < FR) facc[R - st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[st], fb[R], facc[R - st], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            // every fp16 A fragment has been consumed by an issued MFMA (ky = 2 first at R = 2): its 6 KB may be refilled
+                            if (R == 2 && GTTS_WS_EXP != 1) dma16(nch, nst);
+                        }
+                        // ---- fp8 sweep (both cross terms)
+                        [[maybe_unused]] const unsigned long long tv2 = WT_NOW();
+                        if (!fresh && GTTS_WS_EXP != 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                        WT_ADD(7, WT_NOW(), tv2);
+                        i32x8 w8[3];
+#pragma unroll
+                        for (int st = 0; st < 3; ++st) {
+                            const u32x4 q0 = wq[(6 + st * 2) * 64 + lane], q1 = wq[(6 + st * 2 + 1) * 64 + lane];
+                            w8[st][0] = (int)q0[0]; w8[st][1] = (int)q0[1]; w8[st][2] = (int)q0[2]; w8[st][3] = (int)q0[3];
+                            w8[st][4] = (int)q1[0]; w8[st][5] = (int)q1[1]; w8[st][6] = (int)q1[2]; w8[st][7] = (int)q1[3];
+                        }
+                        u32x4 f8l[FR + 2], f8h[FR + 2];
+                        auto fetch8 = [&](int R) {
+                            f8l[R] = x8_p[R * HC + j];
+                            f8h[R] = x8_p[NPIX + R * HC + j];
+                        };
+                        fetch8(0);
+                        fetch8(1);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int R = 0; R < FR + 2; ++R) {
+                            if (R + 2 < FR + 2) fetch8(R + 2);
+                            __builtin_amdgcn_sched_barrier(0);
+                            i32x8 b8;
+                            b8[0] = (int)f8l[R][0]; b8[1] = (int)f8l[R][1]; b8[2] = (int)f8l[R][2]; b8[3] = (int)f8l[R][3];
+                            b8[4] = (int)f8h[R][0]; b8[5] = (int)f8h[R][1]; b8[6] = (int)f8h[R][2]; b8[7] = (int)f8h[R][3];
+#pragma unroll
+                            for (int st = 0; st < 3; ++st)
+                                if (R - st >= 0 && R - st < FR)
+                                    facc[R - st] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8[st], b8, facc[R - st], 0, 0, 0, 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (R == 2 && GTTS_WS_EXP != 1) dma8(nch, nst);
+                        }
+                    }
+                    [[maybe_unused]] const unsigned long long tw2 = WT_NOW();
+                    WT_ADD(1, tw2, tw1);
+                    WT_ADD(3, 1ull, 0ull);
+                    if (!last_c) { ++cc; continue; }
+#if GTTS_WS_TRACE
+                    if (tr_on) {      // ([7]: cycles in the sweeps' vmcnt waits)
+                        if (k == 0) tr_sum[5] = tw2 - tr_entry;
+                        tr_sum[6] = tw2 - tr_entry;
+                    }
+#endif
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile's first two refills land before the stores queue up behind them
+                    WT_ADD(7, WT_NOW(), tw2);
+                    f8_epilogue(par);
+                    cc = 0;
+                    ++k;
+                    tl = decode(k);
+                    WT_ADD(2, WT_NOW(), tw2);
+                }
+            } else
             for (int i = 0; i < nitems; ++i) {
                 [[maybe_unused]] const unsigned long long tw0 = WT_NOW();
                 lds_barrier();                                      // image of item i is complete; everybody is done with item i - 1
@@ -1017,7 +1176,7 @@ void conv3x3_ws_kernel(const ConvArgs a) {
 //     slower at 40 x 512 (92 vs 79 us).
 // LDS of the f16 + fp8 form: two 32-channel images + parameters (mt: 128, or 64 = the 12-wave form of the 64-channel tile)
 bool conv_ws_f8_fits(int cin, int pro, int mt) {
-    return ws_smem_bytes(12 * 34, 2, 2, cin, pro, mt, 2, mt == 128 ? 4 : 2, 4) <= (size_t)160 * 1024;
+    return ws_smem_bytes(12 * 34, 2, 2, cin, pro, mt, 2, mt == 128 ? 4 : 2, 4, mt == 64 ? 2 * WS64_WST16 : 0) <= (size_t)160 * 1024;
 }
 bool conv_ws_eligible(int mode, int c0, int c1, int cout, int pro, int epi, int nsplit, int f16f8) {
     const int cin = c0 + c1;
@@ -1049,8 +1208,11 @@ int conv_ws_nparts(int cout, int Hout, int Wout) {
 #ifndef GTTS_WS_SMALL_WGS
 #define GTTS_WS_SMALL_WGS 160
 #endif
-bool conv_ws_small(int cout, int groups, int Hout, int Wout, int B) {
+bool conv_ws_small(int cout, int groups, int Hout, int Wout, int B, int f16f8) {
     if (groups <= 0 || cout / groups > 32) return false;
+    // f16 + fp8, 64 output channels: ONE form at every batch size (its weights are packed by column stage and it accumulates kx-major:
+    // the 32-channel small form walks row stages) -- a launch smaller than the chip simply runs fewer 12-wave workgroups
+    if (f16f8 && cout == 64) return false;
     const long wgs = (long)B * ((Wout + 31) / 32) * ((Hout + 9) / 10) * (cout % 128 == 0 ? cout / 128 : cout / 64);
     return wgs < GTTS_WS_SMALL_WGS;
 }
@@ -1077,7 +1239,7 @@ static hipError_t launch_ws_ring(ConvArgs &a, hipStream_t st) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         n_cu[dev].store(cus, std::memory_order_relaxed);
     }
-    const size_t smem = ws_smem_bytes(C::NPIX, NPL, RING, a.cin, PRO, C::MT, MF, C::NCW, NKG);
+    const size_t smem = ws_smem_bytes(C::NPIX, NPL, RING, a.cin, PRO, C::MT, MF, C::NCW, NKG, (NSPLIT == 3 && C::NCWP != C::NCW) ? 2 * WS64_WST16 : 0);
     if (smem > (size_t)160 * 1024) return hipErrorInvalidValue;      // (conv_ws_eligible keeps such layers on conv_mfma.hip)
     // persistent workgroups: one per CU for the eight-wave form; the three-wave form fits two per CU (registers: 8 waves)
     const int per_cu = C::NT >= 512 ? 1 : (int)std::min<size_t>(2, (size_t)160 * 1024 / smem);
@@ -1104,7 +1266,7 @@ static hipError_t launch_ws_pro(ConvArgs &a, hipStream_t st) {
 #else
     if (a.act_bf16 || a.nsplit != 2) return hipErrorInvalidValue;
     if (a.f16f8) {
-        if (conv_ws_small(a.cout, a.groups, a.Hout, a.Wout, a.B)) return launch_ws_ring<1, 1, 1, PRO, 3, float>(a, st);
+        if (conv_ws_small(a.cout, a.groups, a.Hout, a.Wout, a.B, 1)) return launch_ws_ring<1, 1, 1, PRO, 3, float>(a, st);
         if (a.cout % 128 != 0) return launch_ws_ring<1, 2, 2, PRO, 3, float>(a, st);      // the 64-channel tile
         return launch_ws_ring<2, 2, 2, PRO, 3, float>(a, st);
     }

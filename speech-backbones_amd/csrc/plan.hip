@@ -1430,7 +1430,7 @@ static std::string conv_kernel_name(int mode, int cin, int cout, int pro, int ep
     const bool wide = cout > 64;
     if (ws) {      // conv_ws.hip (launch_ws_pro)
         char wb[128];
-        const bool sm = conv_ws_small(cout, groups, Ho, Wo, B);
+        const bool sm = conv_ws_small(cout, groups, Ho, Wo, B, f8 ? 1 : 0);
         const int wm = sm ? 1 : (cout % 128 == 0 ? 2 : 1), wn = sm ? 1 : 2;       // (the f16 + fp8 64-channel tile: <1, 2, 2>)
         snprintf(wb, sizeof wb, "gtts::conv3x3_ws_kernel<%d, %d, %d, 5, %d, %d, %s, %d>", wm, wn, sm ? 1 : 2, pro, f8 ? 3 : nsplit,
                  abf ? "__bf16" : "float", f8 ? 2 : 3);

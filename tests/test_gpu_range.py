@@ -100,21 +100,21 @@ def test_activation_range_record(S, dev, conv_ws):
     z, m, mu = inp["z"].to(dev), inp["mask"].to(dev), inp["mu"].to(dev)
     plan.estimator_forward(blob, z, m, mu, t.to(dev))
     assert plan.range_status() == (0, 0.0)
-    # 400x inputs: the residual stream entering the second ResnetBlock's mask-prologue convolution passes |x| = 1024
-    out = plan.estimator_forward(blob, z * 400.0, m, mu * 400.0, t.to(dev))
+    # 50x inputs: the residual stream entering the mask-prologue convolutions passes |x| = 1024 (but not the fp16 half's 65504)
+    out = plan.estimator_forward(blob, z * 50.0, m, mu * 50.0, t.to(dev))
     ev, mx = plan.range_status()
-    print("activation range record at 400x inputs: %d events, max |x| = %.1f" % (ev, mx))
+    print("activation range record at 50x inputs: %d events, max |x| = %.1f" % (ev, mx))
     assert ev > 0 and 1024.0 <= mx < 65504.0
     assert torch.isfinite(out).all()
     # sticky over the step ranges of one sampling run, reset by the next run
-    plan.reverse_diffusion(blob, z * 400.0, m, mu * 400.0, 2)
+    plan.reverse_diffusion(blob, z * 50.0, m, mu * 50.0, 2)
     ev2, mx2 = plan.range_status()
     assert ev2 > 0 and mx2 >= 1024.0
     plan.reverse_diffusion(blob, z, m, mu, 2)
     assert plan.range_status() == (0, 0.0)
     # the other precisions never record
     p3 = S.Plan(precision=S.PREC_BF16X3)
-    p3.estimator_forward(p3.pack(sd, dev), z * 400.0, m, mu * 400.0, t.to(dev))
+    p3.estimator_forward(p3.pack(sd, dev), z * 50.0, m, mu * 50.0, t.to(dev))
     assert p3.range_status() == (0, 0.0)
 
 
@@ -127,6 +127,6 @@ def test_module_range_status(S, dev):
     inp = O.make_inputs(1, 64, seed=4)
     dec(inp["z"].to(dev), inp["mask"].to(dev), inp["mu"].to(dev), 2)
     assert dec.estimator.range_status() == (0, 0.0)
-    dec(inp["z"].to(dev) * 400.0, inp["mask"].to(dev), inp["mu"].to(dev) * 400.0, 2)
+    dec(inp["z"].to(dev) * 50.0, inp["mask"].to(dev), inp["mu"].to(dev) * 50.0, 2)
     ev, mx = dec.estimator.range_status()
     assert ev > 0 and mx >= 1024.0

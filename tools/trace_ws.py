@@ -52,9 +52,11 @@ for i, n in enumerate(["slot wait", "staging", "request setup", "finish_tile"]):
 print("  (first producer wave finish_tile: %.0f)" % p[:, 0, 3].mean())
 
 # phase groups (GTTS_WS_DEPHASE): when the first / last tile epilogue of a consumer wave began, cycles since kernel entry
-grp = c[:, 0, 7]
+grp = c[:, 0, 7] if not os.environ.get('TRACE_W64') else c[:, 0, 7] * 0
 ntile = max(1.0, c[:, :, 3].mean() / float(os.environ.get("TRACE_CHUNKS", "4")))
 for gval in sorted(set(grp.tolist())):
     m = grp == gval
     print("phase group %d: %d workgroups, first epilogue at %.0f, last at %.0f, epilogue cycles per tile %.0f, total %.0f" % (
         int(gval), int(m.sum()), c[m][:, :, 5].mean(), c[m][:, :, 6].mean(), c[m][:, :, 2].mean() / ntile, c[m][:, :, 4].mean()))
+if os.environ.get("TRACE_W64"):
+    print("64-channel tile (weights through the LDS ring): vmcnt(0) waits of the stages %.0f cycles per item" % (c[:, :, 7].mean() / items))
