@@ -84,6 +84,21 @@ namespace gtts {
 #ifndef GTTS_WS64_LEAD
 #define GTTS_WS64_LEAD 96
 #endif
+// the 64-channel f16 + fp8 tile (W64): sweep pipelining (0: a sweep reads its A fragments and first B rows itself; 1: the previous sweep
+// prefetches them at input row GTTS_W64_PFROW; 2: A fragments only), B rows fetched GTTS_W64_DIST rows ahead, ring refill after row
+// GTTS_W64_DMAROW (>= 2: every A fragment of the sweep has been consumed by then)
+#ifndef GTTS_W64_PF
+#define GTTS_W64_PF 0
+#endif
+#ifndef GTTS_W64_DIST
+#define GTTS_W64_DIST 2
+#endif
+#ifndef GTTS_W64_PFROW
+#define GTTS_W64_PFROW 5
+#endif
+#ifndef GTTS_W64_DMAROW
+#define GTTS_W64_DMAROW 2
+#endif
 #ifndef GTTS_WS_LEAD
 #define GTTS_WS_LEAD 160
 #endif
@@ -482,8 +497,25 @@ void conv3x3_ws_kernel(const ConvArgs a) {
                     for (int p = 0; p < 6; ++p)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_vp)(wq + (6 + p) * 64), 16, src8, so + (((p >> 1) * NKG + (p & 1)) * 64) * 16, 0, 0);
                 };
-                if (nitems > 0) { dma16(0, 0); dma8(0, 0); }
-                if (GTTS_WS_EXP == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (ablation: the ring is filled once)
+                // The six sweeps of an item are software-pipelined: while a sweep works on its last input rows (R == 5) it reads the NEXT
+                // sweep's six A fragments and first two B rows (behind a vmcnt(6) for the refill they come from), so a sweep starts with
+                // its operands in registers -- without that every sweep opened on an exposed LDS round trip (A + two B rows, ~300-400
+                // cycles, six times per item: level-0 launches 273 / 267 us).  Only the first sweep of an item reads its two B rows after the
+                // item barrier (the image is not complete before it).
+                u32x4 Acur[6], Anext[6], Bn[GTTS_W64_DIST][2];
+                auto readA = [&](u32x4 (&A)[6], int piece0) {
+#pragma unroll
+                    for (int p = 0; p < 6; ++p) A[p] = wq[(piece0 + p) * 64 + lane];
+                };
+                if (nitems > 0) {
+                    dma16(0, 0);
+                    dma8(0, 0);
+                    if (GTTS_W64_PF != 0) {
+                        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                        readA(Acur, 0);
+                    }
+                    if (GTTS_WS_EXP == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (ablation: the ring is filled once)
+                }
                 for (int i = 0; i < nitems; ++i) {
                     const int par = k & 1;
                     const u32x4 *xh_p = s_img + slot * IMG16 + xl0;                                  // fp16 plane, k-step 0 (k-step 1: + 2 NPIX)
@@ -494,80 +526,85 @@ void conv3x3_ws_kernel(const ConvArgs a) {
                     lds_barrier();                  // image of item i is complete; everybody is done with item i - 1
                     [[maybe_unused]] const unsigned long long tw1 = WT_NOW();
                     WT_ADD(0, tw1, tw0);
+                    auto readB = [&](u32x4 (&b)[2], int R, int j, bool f8s) {      // the B fragment (pair) of input row R at column shift j
+                        if (!f8s) { b[0] = xh_p[R * HC + j]; b[1] = xh_p[2 * NPIX + R * HC + j]; }
+                        else { b[0] = x8_p[R * HC + j]; b[1] = x8_p[NPIX + R * HC + j]; }
+                    };
+                    if (GTTS_W64_PF == 1) {
+#pragma unroll
+                        for (int d = 0; d < GTTS_W64_DIST; ++d) readB(Bn[d], d, 0, false);
+                    }
                     if (cc == 0) {
 #pragma unroll
                         for (int r = 0; r < FR; ++r)
 #pragma unroll
                             for (int e = 0; e < 16; ++e) facc[r][e] = 0.f;
                     }
+                    const bool fresh = i != 0 && cc == 0;             // first stage after an epilogue: both ring halves landed before it
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const bool fresh = i == 0 ? false : (cc == 0 && j == 0);     // first stage after an epilogue: both halves landed before it
+                    for (int s = 0; s < 6; ++s) {
+                        const int j = s >> 1;
+                        const bool f8s = (s & 1) != 0;
                         const int nch = j == 2 ? (last_c ? 0 : cc + 1) : cc, nst = j == 2 ? 0 : j + 1;      // the next stage (after the last item: block 0 again, never read)
-                        // ---- f16 sweep
-                        [[maybe_unused]] const unsigned long long tv0 = WT_NOW();
-                        if (!fresh && GTTS_WS_EXP != 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                        WT_ADD(7, WT_NOW(), tv0);
-                        f16x8 wa[3], wb[3];
-#pragma unroll
-                        for (int st = 0; st < 3; ++st) {
-                            wa[st] = __builtin_bit_cast(f16x8, wq[(st * 2) * 64 + lane]);
-                            wb[st] = __builtin_bit_cast(f16x8, wq[(st * 2 + 1) * 64 + lane]);
+                        u32x4 Bw[FR + 2][2];
+                        if (GTTS_W64_PF == 0) {
+                            [[maybe_unused]] const unsigned long long tv0 = WT_NOW();
+                            if (GTTS_WS_EXP != 1 && !(fresh && j == 0)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                            WT_ADD(7, WT_NOW(), tv0);
+                            readA(Acur, f8s ? 6 : 0);
                         }
-                        f16x8 fa[FR + 2], fb[FR + 2];
-                        auto fetch16 = [&](int R) {
-                            fa[R] = __builtin_bit_cast(f16x8, xh_p[R * HC + j]);
-                            fb[R] = __builtin_bit_cast(f16x8, xh_p[2 * NPIX + R * HC + j]);
-                        };
-                        fetch16(0);
-                        fetch16(1);
+                        if (GTTS_W64_PF == 1) {
+#pragma unroll
+                            for (int d = 0; d < GTTS_W64_DIST; ++d) { Bw[d][0] = Bn[d][0]; Bw[d][1] = Bn[d][1]; }
+                        } else {
+#pragma unroll
+                            for (int d = 0; d < GTTS_W64_DIST; ++d) readB(Bw[d], d, j, f8s);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int R = 0; R < FR + 2; ++R) {
-                            if (R + 2 < FR + 2) fetch16(R + 2);
-                            __builtin_amdgcn_sched_barrier(0);
+                            if (R + GTTS_W64_DIST < FR + 2) readB(Bw[R + GTTS_W64_DIST], R + GTTS_W64_DIST, j, f8s);
+                            if (GTTS_W64_PF != 0 && R == GTTS_W64_PFROW) {
+                                // operands of the next sweep: its A fragments come from the ring half refilled one stage ago
+                                [[maybe_unused]] const unsigned long long tv0 = WT_NOW();
+                                if (GTTS_WS_EXP != 1 && !(fresh && s == 0)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                                WT_ADD(7, WT_NOW(), tv0);
+                                readA(Anext, f8s ? 0 : 6);
+                                if (GTTS_W64_PF == 1 && s < 5) {
 #pragma unroll
-                            for (int st = 0; st < 3; ++st)
-                                if (R - st >= 0 && R - st < FR) facc[R - st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[st], fa[R], facc[R - st], 0, 0, 0);
-#pragma unroll
-                            for (int st = 0; st < 3; ++st)
-                                if (R - st >= 0 && R - st < FR) facc[R - st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[st], fb[R], facc[R - st], 0, 0, 0);
+                                    for (int d = 0; d < GTTS_W64_DIST; ++d) readB(Bn[d], d, (s + 1) >> 1, !f8s);
+                                }
+                            }
                             __builtin_amdgcn_sched_barrier(0);
-                            // every fp16 A fragment has been consumed by an issued MFMA (ky = 2 first at R = 2): its 6 KB may be refilled
-                            if (R == 2 && GTTS_WS_EXP != 1) dma16(nch, nst);
+                            if (!f8s) {
+#pragma unroll
+                                for (int st = 0; st < 3; ++st)
+                                    if (R - st >= 0 && R - st < FR)
+                                        facc[R - st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Acur[st * 2]), __builtin_bit_cast(f16x8, Bw[R][0]), facc[R - st], 0, 0, 0);
+#pragma unroll
+                                for (int st = 0; st < 3; ++st)
+                                    if (R - st >= 0 && R - st < FR)
+                                        facc[R - st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Acur[st * 2 + 1]), __builtin_bit_cast(f16x8, Bw[R][1]), facc[R - st], 0, 0, 0);
+                            } else {
+                                i32x8 b8;
+                                b8[0] = (int)Bw[R][0][0]; b8[1] = (int)Bw[R][0][1]; b8[2] = (int)Bw[R][0][2]; b8[3] = (int)Bw[R][0][3];
+                                b8[4] = (int)Bw[R][1][0]; b8[5] = (int)Bw[R][1][1]; b8[6] = (int)Bw[R][1][2]; b8[7] = (int)Bw[R][1][3];
+#pragma unroll
+                                for (int st = 0; st < 3; ++st)
+                                    if (R - st >= 0 && R - st < FR) {
+                                        i32x8 a8;
+                                        a8[0] = (int)Acur[st * 2][0]; a8[1] = (int)Acur[st * 2][1]; a8[2] = (int)Acur[st * 2][2]; a8[3] = (int)Acur[st * 2][3];
+                                        a8[4] = (int)Acur[st * 2 + 1][0]; a8[5] = (int)Acur[st * 2 + 1][1]; a8[6] = (int)Acur[st * 2 + 1][2]; a8[7] = (int)Acur[st * 2 + 1][3];
+                                        facc[R - st] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, facc[R - st], 0, 0, 0, 0, 0, 0);
+                                    }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            // every A fragment of this sweep has been consumed by an issued MFMA (ky = 2 first at R = 2): its ring half may be refilled
+                            if (R == GTTS_W64_DMAROW && GTTS_WS_EXP != 1) { if (!f8s) dma16(nch, nst); else dma8(nch, nst); }
                         }
-                        // ---- fp8 sweep (both cross terms)
-                        [[maybe_unused]] const unsigned long long tv2 = WT_NOW();
-                        if (!fresh && GTTS_WS_EXP != 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                        WT_ADD(7, WT_NOW(), tv2);
-                        i32x8 w8[3];
+                        if (GTTS_W64_PF != 0) {
 #pragma unroll
-                        for (int st = 0; st < 3; ++st) {
-                            const u32x4 q0 = wq[(6 + st * 2) * 64 + lane], q1 = wq[(6 + st * 2 + 1) * 64 + lane];
-                            w8[st][0] = (int)q0[0]; w8[st][1] = (int)q0[1]; w8[st][2] = (int)q0[2]; w8[st][3] = (int)q0[3];
-                            w8[st][4] = (int)q1[0]; w8[st][5] = (int)q1[1]; w8[st][6] = (int)q1[2]; w8[st][7] = (int)q1[3];
-                        }
-                        u32x4 f8l[FR + 2], f8h[FR + 2];
-                        auto fetch8 = [&](int R) {
-                            f8l[R] = x8_p[R * HC + j];
-                            f8h[R] = x8_p[NPIX + R * HC + j];
-                        };
-                        fetch8(0);
-                        fetch8(1);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int R = 0; R < FR + 2; ++R) {
-                            if (R + 2 < FR + 2) fetch8(R + 2);
-                            __builtin_amdgcn_sched_barrier(0);
-                            i32x8 b8;
-                            b8[0] = (int)f8l[R][0]; b8[1] = (int)f8l[R][1]; b8[2] = (int)f8l[R][2]; b8[3] = (int)f8l[R][3];
-                            b8[4] = (int)f8h[R][0]; b8[5] = (int)f8h[R][1]; b8[6] = (int)f8h[R][2]; b8[7] = (int)f8h[R][3];
-#pragma unroll
-                            for (int st = 0; st < 3; ++st)
-                                if (R - st >= 0 && R - st < FR)
-                                    facc[R - st] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8[st], b8, facc[R - st], 0, 0, 0, 0, 0, 0);
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (R == 2 && GTTS_WS_EXP != 1) dma8(nch, nst);
+                            for (int p = 0; p < 6; ++p) Acur[p] = Anext[p];
                         }
                     }
                     [[maybe_unused]] const unsigned long long tw2 = WT_NOW();
