@@ -142,8 +142,9 @@ int gtts_pack_weights(const gtts_plan *plan, const void *const *param_ptrs, int 
                       void *packed, gtts_stream_t stream);
 
 /* ABI 6.  Activation range record of the last gtts_estimator_forward / gtts_reverse_diffusion (or gtts_vc_*) call that used
- * `workspace` (GTTS_PREC_F16F8 plans; zero for the other precisions): *n_events = number of staging lanes x launches that split
- * an activation with |x| >= 1024, *max_abs = the largest |x| they saw (0 when n_events == 0).  Sticky over the step ranges of one
+ * `workspace`: *n_events = number of staging lanes x launches that split an activation with |x| >= 1024 (GTTS_PREC_F16F8 plans
+ * only), plus -- in every precision -- (samples x Block convolutions) whose GroupNorm statistics came out non-finite;
+ * *max_abs = the largest |x| seen (inf for a non-finite one; 0 when n_events == 0).  Sticky over the step ranges of one
  * sampling run (reset where step_begin == 0, and by every estimator call).  This query -- and gtts_pack_weights of an F16F8 plan --
  * are the only calls of the ABI that SYNCHRONISE `stream`; do not call them inside a stream capture. */
 int gtts_workspace_status(const void *workspace, unsigned *n_events, float *max_abs, gtts_stream_t stream);

@@ -14,6 +14,7 @@
 //                       packed bf16 hi/lo layout of the 1x1 MFMA convolution; bias_b = g * b
 //   pass 2  conv_mfma CONV_P1 with per-sample weights and EPI_ATTN (+ x): reads x once, writes once.
 // Softmax quirks kept: over ALL h*w positions, no mask, no 1/sqrt(d) scaling, q not normalised.
+#include <cstring>
 #include "common.h"
 #include "kernels.h"
 
@@ -27,6 +28,7 @@ struct AttnCtxArgs {
     const unsigned char *wkv;
     float *partials;
     int C, HW, nstage, tiles, tps, nrec, nsplit, B;
+    AttnTail tail;          // attn_ctx64_kernel<..., TAIL = 1>: the fused identity tail (x is written by the launch)
 };
 
 __device__ __forceinline__ void pack8_split(const float (&v)[8], u32x4 &hi, u32x4 &lo) {
@@ -304,7 +306,11 @@ __global__ __launch_bounds__(256 * HPW, HPW == 1 ? 2 : 1) void attn_ctx_kernel(c
 // LDS region for the whole workgroup, so nothing but the x image is shared: two workgroup barriers per tile (the per-head
 // kernel: four per 256-pixel tile, i.e. sixteen per 4 x 64 pixels).  Per wave and tile: 48 projection MFMAs + the online
 // softmax + 12 context MFMAs, exactly the unit of work of the per-head kernel; records go out per wave (= per head).
-template <int NSPLIT, typename AT>
+// TAIL: the ResnetBlock's identity tail rides in the staging step (round-5 review item 5: tail_identity wrote the tensor this kernel
+// then read back -- two passes over 335 MB at level 0): the thread that stages (8 channels, pixel n) loads the block's input and the
+// raw output of its second convolution instead, forms x = xin m + Mish(h sc + sh) m exactly as tail_identity_kernel does, stores it (the
+// apply pass and the skip connection read it later) and stages it.  One read of the tensor less per attention block.
+template <int NSPLIT, typename AT, int TAIL = 0>
 __global__ __launch_bounds__(256, 2) void attn_ctx64_kernel(const AttnCtxArgs a) {
     constexpr int AB = (int)sizeof(AT);
     constexpr int C = 64, NKGT = C / 8;                         // 8 channel groups of 8
@@ -342,6 +348,27 @@ __global__ __launch_bounds__(256, 2) void attn_ctx64_kernel(const AttnCtxArgs a)
         reinterpret_cast<void *>(((unsigned long long)xhi << 32) | xlo), 0, __builtin_amdgcn_readfirstlane(xbytes), 0x00020000);
     // staging items: thread -> (channel group kg = it * 4 + wave, pixel = lane); the channel offset is wave-uniform
     float raw[2][8];
+    [[maybe_unused]] float rawh[2][8], tsc[2][8], tsh[2][8], tmask = 0.f;
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rsh = rsx, rsi = rsx;
+    if constexpr (TAIL) {
+        static_assert(!TAIL || AB == 4, "the fused tail is the fp32-storage form");
+        auto mk = [&](const void *p) {
+            const unsigned long long u = reinterpret_cast<unsigned long long>(reinterpret_cast<const AT *>(p) + (size_t)b * C * a.HW);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+            return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0,
+                                                     __builtin_amdgcn_readfirstlane(xbytes), 0x00020000);
+        };
+        rsh = mk(a.tail.h);
+        rsi = mk(a.tail.xin);
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = (it * 4 + wave) * 8 + i;
+                tsc[it][i] = a.tail.esc[(size_t)b * C + c];
+                tsh[it][i] = a.tail.esh[(size_t)b * C + c];
+            }
+    }
     auto load = [&](int tile) {
         const int n = tile * 64 + lane;
         const int voff = n < a.HW ? n * AB : xbytes;               // beyond the sample: the bounds check returns 0
@@ -350,9 +377,29 @@ __global__ __launch_bounds__(256, 2) void attn_ctx64_kernel(const AttnCtxArgs a)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int c = (it * 4 + wave) * 8 + i;
-                if constexpr (AB == 4) raw[it][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, voff, c * a.HW * 4, 0));
+                if constexpr (TAIL) {
+                    raw[it][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsi, voff, c * a.HW * 4, 0));
+                    rawh[it][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsh, voff, c * a.HW * 4, 0));
+                } else if constexpr (AB == 4) raw[it][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, voff, c * a.HW * 4, 0));
                 else raw[it][i] = __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsx, voff, c * a.HW * 2, 0) << 16);
             }
+        if constexpr (TAIL) tmask = n < a.HW ? a.tail.mask[(size_t)b * a.tail.T + ((size_t)(n % a.tail.W) << a.tail.lvl)] : 0.f;
+    };
+    // the fused tail: turn the loaded (xin, h) pair of the tile into the block's output, store it, keep it for staging
+    auto apply_tail = [&](int tile) {
+        if constexpr (TAIL) {
+            const int n = tile * 64 + lane;
+            const int voff = n < a.HW ? n * AB : xbytes;           // (stores beyond the sample are dropped by the bounds check)
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = (it * 4 + wave) * 8 + i;
+                    const float v = tail_value(rawh[it][i], raw[it][i], tsc[it][i], tsh[it][i], tmask);
+                    raw[it][i] = v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsx, voff, c * a.HW * 4, 0);
+                }
+        }
     };
 
     const float NEG_INF = -__builtin_inff();
@@ -363,6 +410,7 @@ __global__ __launch_bounds__(256, 2) void attn_ctx64_kernel(const AttnCtxArgs a)
 
     load(tile0);
     for (int tile = tile0; tile < tile1; ++tile) {
+        apply_tail(tile);
         lds_barrier();                                  // every head is done with the previous tile's image (first pass: s_w is written)
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -500,10 +548,13 @@ __global__ __launch_bounds__(256, 2) void attn_ctx64_kernel(const AttnCtxArgs a)
 }
 
 hipError_t launch_attn_ctx(const void *x, const unsigned char *wkv, float *partials, int B, int C, int HW, int nsplit,
-                           hipStream_t st, int act_bf16) {
+                           hipStream_t st, int act_bf16, const AttnTail *tail) {
     AttnGeom g = attn_geom(HW, C);
     if ((size_t)C * HW * 4 >= ((size_t)1 << 31)) return hipErrorInvalidValue;     // 32-bit offsets in the buffer descriptor
+    if (tail != nullptr && (!attn_head_per_wave(C) || act_bf16)) return hipErrorInvalidValue;
     AttnCtxArgs a;
+    memset(&a, 0, sizeof(a));
+    if (tail != nullptr) a.tail = *tail;
     a.x = x; a.wkv = wkv; a.partials = partials; a.C = C; a.HW = HW;
     a.nstage = (C + 16 * ATTN_KCH - 1) / (16 * ATTN_KCH);
     a.tiles = g.tiles; a.tps = g.tps; a.nrec = g.nrec; a.nsplit = nsplit; a.B = B;
@@ -513,6 +564,9 @@ hipError_t launch_attn_ctx(const void *x, const unsigned char *wkv, float *parti
         if (act_bf16) {
             if (nsplit > 1) return hipErrorInvalidValue;
             hipLaunchKernelGGL((attn_ctx64_kernel<1, __bf16>), grid64, dim3(256), 0, st, a);
+        } else if (tail != nullptr) {
+            if (nsplit > 1) hipLaunchKernelGGL((attn_ctx64_kernel<2, float, 1>), grid64, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((attn_ctx64_kernel<1, float, 1>), grid64, dim3(256), 0, st, a);
         } else if (nsplit > 1) hipLaunchKernelGGL((attn_ctx64_kernel<2, float>), grid64, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((attn_ctx64_kernel<1, float>), grid64, dim3(256), 0, st, a);
         return hipGetLastError();

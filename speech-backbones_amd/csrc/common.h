@@ -64,6 +64,25 @@ __device__ __forceinline__ float mish_f(float x) {
     return x * (n * __builtin_amdgcn_rcpf(n + 2.0f));
 }
 
+// v * m for a mask factor m that is 0 or 1 (or a mask value), with 0 * anything == 0 -- v_mul_legacy_f32.  The persistent convolution's
+// 16-byte halo loads reach up to a frame in front of / three frames behind a tensor (conv_ws.hip: the neighbouring tensor's bytes, or
+// workspace the caller never initialised); those positions carry m = 0, and an IEEE multiply would turn a NaN / Inf found there into a NaN
+// of the result (found in round 6: after ONE overflowing call every later call on the same workspace returned NaN).  Finite operands:
+// identical to v_mul_f32.
+__device__ __forceinline__ float mul_mask0(float v, float m) {
+    float r;
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(m));
+    return r;
+}
+
+// The ResnetBlock identity tail of one element (Grad-TTS/model/diffusion.py:72,78): out = x m + Mish(GN(h)) m with GN(h) = h sc + sh.
+// ONE definition for tail_identity_kernel (misc.hip) and the tail fused into the attention context pass (attn.hip): both forms of
+// the same tensor must agree bit for bit, so nothing here is left to per-file contraction choices.
+__device__ __forceinline__ float tail_value(float h, float x, float sc, float sh, float m) {
+#pragma clang fp contract(off)
+    return fmaf(mish_f(fmaf(h, sc, sh)), m, x * m);
+}
+
 // fp32 -> (hi, lo) bf16 pair with hi + lo == x to ~2^-17 relative (both round-to-nearest-even).
 __device__ __forceinline__ void split_bf16(float x, __bf16 &h, __bf16 &l) {
     h = (__bf16)x;
@@ -114,6 +133,8 @@ __device__ __forceinline__ void f8_cross_pair(float x0, float x1, _Float16 h0, _
 // it splits (one v_max3_f32 per value pair); a lane that saw |x| >= 1024 -- the smallest magnitude whose fp16 residual can exceed the
 // fp8 cross-term range, i.e. from where on an element is carried at fp16 grade only -- adds one event and the maximum to the caller's
 // record when its kernel ends: {unsigned events, bit pattern of max |x|} at the start of the workspace (gtts_workspace_status).
+// NaN operands do not raise the running maximum (v_max_f32 returns the other operand); they are caught where they surface: a
+// Block convolution whose GroupNorm statistics come out non-finite adds an event with max |x| = inf from its fused finalize.
 constexpr float F8_ACT_LIMIT = 1024.0f;
 __device__ __forceinline__ float f8_range_track(float m, float a, float b) { return fmaxf(fmaxf(m, fabsf(a)), fabsf(b)); }
 __device__ __forceinline__ void f8_range_note(unsigned *rec, float m) {
@@ -286,6 +307,13 @@ static inline size_t conv_packed_bytes(int mode, int cin, int cout) {
 }
 
 hipError_t launch_conv(int mode, const ConvArgs &a, hipStream_t st);
+// GTTS_W64_RING=1 builds (A/B only): the 64-channel f16 + fp8 tile of conv_ws.hip takes its weights through per-wave LDS rings filled by
+// LDS-DMA, in column stages (round 6; conv_ws.hip, "W64").  Built, parity-green, measured on one box against the register-load kernel:
+// 275 / 261 us against 266 / 259 per level-0 launch -- not adopted (profiles/NEGATIVE_RESULTS.md).  The switch also selects the weight
+// packing of those layers (pack.hip: column stages) and keeps them off the small-launch form.
+#ifndef GTTS_W64_RING
+#define GTTS_W64_RING 0
+#endif
 // conv_ws.hip: the persistent wave-specialised Block convolution.  GTTS_WS=0 builds (A/B only) keep every layer on conv_mfma.hip.
 #ifndef GTTS_WS
 #define GTTS_WS 1
@@ -302,7 +330,7 @@ hipError_t launch_conv_up4(const ConvArgs &a, hipStream_t st);
 // footprint that leaves two workgroups per CU.  Decides the packing of the layer's weights as well (pack.hip).
 // use_ws: the plan runs eligible layers on the persistent kernel (gtts_unet_cfg.conv_ws) -- 64-channel layers take the split only there.
 bool conv_f16f8_ok(int mode, int c0, int c1, int cout, int pro, int epi, int use_ws);
-bool conv_ws_f8_fits(int cin, int pro, int mt);
+bool conv_ws_f8_fits(int cin, int pro, int mt, int cout);
 bool conv_small_tiles(int mode, int cout, int Hout, int Wout, int B);   // half-height tiles for launches smaller than the chip
 bool conv_rowpair_stats(int mode, int cout, int Hout, int Wout);        // GroupNorm partial slots per row pair (batch-size independent)
 

@@ -959,6 +959,10 @@ __global__ __launch_bounds__(256, (PRO == PRO_IGLU || MODE == CONV_C7) ? 2 : (PR
                 double var = fma(-mean, mean, s2 / (double)a.gn_count);
                 if (var < 0.0) var = 0.0;
                 const double rstd = 1.0 / sqrt(var + 1e-5);
+                // non-finite statistics = a non-finite output of this convolution (in GTTS_PREC_F16F8: an activation beyond the fp16 half's
+                // range, or what such a value turned into downstream): one event with max |x| = inf in the call's range record (common.h);
+                // the staging kernels' own running maximum ignores NaN (v_max_f32), so this is where a NaN becomes visible to the caller
+                if (g < a.groups && sub == 0 && !(fabs(s1) < 1.0e300 && s2 < 1.0e300)) f8_range_note(a.sat, __builtin_inff());
                 if (g < a.groups) {
                     for (int c = g * gs + sub; c < (g + 1) * gs; c += 8) {
                         const double sc = (double)a.gn_gamma[c] * rstd;
@@ -1034,7 +1038,7 @@ bool conv_f16f8_ok(int mode, int c0, int c1, int cout, int pro, int epi, int use
     // tile was built and measured (round 5, same box, us per launch at B = 16): 219.6 / 209.9 (mask / GroupNorm prologue) against
     // 214.2 / 186.5 in bf16x3 -- two workgroups per CU (68 KB of LDS at 32-channel chunks) instead of three, twice the staging per MFMA,
     // and LDS fragment traffic that no longer hides behind the shorter MFMA phase; those instances are gone.
-    if (cout == 64) return GTTS_WS && GTTS_F8_WS64 && use_ws && cin >= 64 && conv_ws_f8_fits(cin, pro, 64);
+    if (cout == 64) return GTTS_WS && GTTS_F8_WS64 && use_ws && cin >= 64 && conv_ws_f8_fits(cin, pro, 64, cout);
     if (cout % 128 != 0) return false;
     const ConvGeom g = conv_geom(mode, cin, cout, 1);
     const int npix = (g.TR + 2) * 34, nkg = 2 * g.kch;

@@ -144,10 +144,10 @@ struct WsCfg {
 // nsplit planes (1: hi; 2: hi + lo, or fp16 hi + fp8 cross-term operands) of nkg 8-channel groups per ring slot
 // wq16: 16-byte units of the weight ring (the f16 + fp8 64-channel tile keeps two (chunk, column stage) weight blocks in LDS)
 constexpr int WS64_WST16 = 3 * 64 * 2 * 4;      // one block: [split][tap = ky][kg / g][64 couts] x 16 B = 24 KB
-static inline size_t ws_smem_bytes(int npix, int nsplit, int ring, int cin, int pro, int mt, int mf, int ncw, int nkg = 2, int wq16 = 0) {
+static inline size_t ws_smem_bytes(int npix, int nsplit, int ring, int cin, int pro, int cout, int mf, int ncw, int nkg = 2, int wq16 = 0) {
     const size_t cpad = (size_t)((cin + 31) / 32) * 32;
     return (size_t)ring * nsplit * nkg * npix * 16 + (size_t)wq16 * 16 + (pro == PRO_GN ? (size_t)2 * 3 * cpad * 4 : 0) +
-           (size_t)2 * ncw * mf * 8 * 4 + (size_t)2 * mt * 4;
+           (size_t)2 * ncw * mf * 8 * 4 + (size_t)((cout + 63) / 64) * 64 * 4;
 }
 
 // NSPLIT == 3: the f16 + fp8 split of GTTS_PREC_F16F8 (common.h) on 32-channel chunks: plane 0 of an image holds fp16 hi values
@@ -173,13 +173,15 @@ void conv3x3_ws_kernel(const ConvArgs a) {
     const int WBLK16 = 3 * MTP * 2 * NKG;
     static_assert(PRO == PRO_MASK || PRO == PRO_GN, "Block prologues only");
 
-    // W64: the 12-wave 64-channel tile of the f16 + fp8 form.  Its weights do NOT come through the vector L1 tap by tap: the CU's L1
+    // W64 (GTTS_W64_RING builds only -- measured, not adopted: same box, us per level-0 64 -> 64 launch with the GroupNorm / mask
+    // prologue: 266.4 / 258.5 for the register-load loop below against 274.6-275.4 / 259.8-262.5 for this form; ups.1.0.b1 189 vs 193):
+    // the 12-wave 64-channel tile of the f16 + fp8 form.  Its weights do NOT come through the vector L1 tap by tap: the CU's L1
     // returns loads in order, and behind the producers' HBM-miss halo loads an L2-hit fragment load waits ~1000-1500 cycles at 32 KB in
     // flight, ~3000 at this tile's 52 KB (tools/probe/mem_probe.hip; round 5: chunk loop 10.25k cycles for 5.76k of MFMA issue, 7.05k
     // without weight reloads).  Instead every consumer wave streams its block's A fragments of one (chunk, COLUMN stage) -- the three taps
     // (ky = 0..2) of one kx -- into 12 KB of LDS of its own with LDS-DMA (buffer_load ... lds: no registers, a whole stage = 1920 MFMA
     // cycles ahead of their use) and reads them from there; see the consumer loop.  Column stages also let a B fragment serve three taps.
-    constexpr bool W64 = F8 && C::NCWP != C::NCW;
+    constexpr bool W64 = GTTS_W64_RING && F8 && C::NCWP != C::NCW;
     constexpr int WQ16 = W64 ? 2 * WS64_WST16 : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4 *s_img = reinterpret_cast<u32x4 *>(smem);                      // [RING][split][kg][NPIX]
@@ -187,7 +189,7 @@ void conv3x3_ws_kernel(const ConvArgs a) {
     const int cpad = a.nchunk * CH;
     float *s_par = reinterpret_cast<float *>(s_img + RING * IMG16 + WQ16);   // PRO_GN: [2 (tile parity)][3][cpad] scale, shift, time bias
     float *s_red = s_par + (PRO == PRO_GN ? 2 * 3 * cpad : 0);           // [2 (tile parity)][NCW waves][MF][4 octets][2]
-    float *s_epi = s_red + 2 * NCW * MF * 8;                             // [2 (tile parity)][MT] bias
+    float *s_epi = s_red + 2 * NCW * MF * 8;                             // [cout] bias of every output channel, written once (prologue)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -289,7 +291,7 @@ void conv3x3_ws_kernel(const ConvArgs a) {
                 for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { st1[mi][q] = 0.f; st2[mi][q] = 0.f; }
-                const float *bias_l = s_epi + par * MT + m0 + 4 * kg_l;
+                const float *bias_l = s_epi + tl.cot * MT + m0 + 4 * kg_l;
                 // (Measured and dropped: a 4 x 4 transpose inside every lane quad -- DPP exchanges + bit-selects -- so that a lane
                 // holds four consecutive frames of one channel and stores 16 bytes.  A quarter of the store instructions, but
                 // each then touches 8 channel rows instead of 2: epilogue 12.9k vs 9.9k cycles per 128-channel tile.)
@@ -344,12 +346,10 @@ void conv3x3_ws_kernel(const ConvArgs a) {
                     }
                 }
         };
-        if constexpr (W64) {
-            // the first (chunk 0, column stage 0) block of the weight ring, landed before anybody passes the prologue barrier
-            // one cout tile (cout == MT == 64): the bias is the same for every tile -- written once, into both parities (a load per tile
-            // would put an s_waitcnt vmcnt(0) behind the previous epilogue's stores at every tile start)
-            for (int c = tid; c < 2 * MT; c += NCT) s_epi[c] = a.bias[c % MT];
-        }
+        // the layer's whole bias vector, once: a load per tile (as before round 6) put an s_waitcnt vmcnt(0) behind the previous tile's
+        // epilogue stores at every tile start -- the consumers then waited for up to 63 stores per wave to be acknowledged before their
+        // first MFMA of the next tile instead of leaving them to drain behind it
+        for (int c = tid; c < a.cout; c += NCT) s_epi[c] = a.bias[c];
         lds_barrier();                                              // (P) prologue barrier: s_par of tile 0 is written
         int k = 0, cc = 0, slot = 0;
         if constexpr (F8) {
@@ -413,7 +413,7 @@ void conv3x3_ws_kernel(const ConvArgs a) {
                     uniform_rsrc(reinterpret_cast<AT *>(a.out) + (size_t)tl.b * a.cout * HW, out_bytes);
                 const int ch0 = tl.cot * MT + fm0;
                 const bool col_ok = oxx < a.Wout;
-                const float *bias_l = s_epi + par * MT + fm0 + 4 * kg_l;
+                const float *bias_l = s_epi + tl.cot * MT + fm0 + 4 * kg_l;
 #pragma unroll
                 for (int lb = 0; lb < FR / 5; ++lb) {
                     const int band = bnd * (FR / 5) + lb;             // 5-row band of the tile
@@ -650,7 +650,6 @@ void conv3x3_ws_kernel(const ConvArgs a) {
                     for (int r = 0; r < FR; ++r)
 #pragma unroll
                         for (int e = 0; e < 16; ++e) facc[r][e] = 0.f;
-                    for (int c = tid; c < MT; c += NCT) s_epi[par * MT + c] = a.bias[tl.cot * MT + c];
                 }
                 // activation fragments of the tap in flight: one variable per slot (dead ones are reused by the register allocator)
                 f16x8 fa[FR], fb[FR];
@@ -750,7 +749,6 @@ void conv3x3_ws_kernel(const ConvArgs a) {
                     for (int ni = 0; ni < NF; ++ni)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-                for (int c = tid; c < MT; c += NCT) s_epi[par * MT + c] = a.bias[tl.cot * MT + c];
             } else if (RING < 3) {
 #pragma unroll
                 for (int ni = 0; ni < NF; ++ni) xh[ni] = *reinterpret_cast<const bf16x8 *>(xh_p + ni * HC);
@@ -968,10 +966,10 @@ void conv3x3_ws_kernel(const ConvArgs a) {
                             }
                             const float m = m_cur[it][j];
                             if constexpr (PRO == PRO_MASK) {
-                                v *= m;
+                                v = mul_mask0(v, m);                 // (m == 0 also marks frames outside the tensor: NaN-proof, common.h)
                             } else {
                                 const float y = fmaf(v, sc[i], sh[i]);
-                                v = fmaf(mish_f(y), m, tb[i]) * m;
+                                v = mul_mask0(fmaf(mish_f(y), m, tb[i]), m);
                             }
                             if constexpr (F8) {
                                 const _Float16 h = (_Float16)v;
@@ -1107,6 +1105,10 @@ void conv3x3_ws_kernel(const ConvArgs a) {
             double var = fma(-mean, mean, s2 / (double)a.gn_count);
             if (var < 0.0) var = 0.0;
             const double rstd = 1.0 / sqrt(var + 1e-5);
+            // non-finite statistics = a non-finite output of this convolution (in GTTS_PREC_F16F8: an activation beyond the fp16 half's
+            // range, or what such a value turned into downstream): one event with max |x| = inf in the call's range record (common.h);
+            // the staging kernels' own running maximum ignores NaN (v_max_f32), so this is where a NaN becomes visible to the caller
+            if (g < a.groups && sub == 0 && !(fabs(s1) < 1.0e300 && s2 < 1.0e300)) f8_range_note(a.sat, __builtin_inff());
             if (g < a.groups) {
                 for (int c = g * gs + sub; c < (g + 1) * gs; c += 8) {
                     const double sc = (double)a.gn_gamma[c] * rstd;
@@ -1212,8 +1214,8 @@ void conv3x3_ws_kernel(const ConvArgs a) {
 //     the epilogue over; a 64 x 640 form of this kernel was level with conv_mfma.hip at 80 x 1024 (300 vs 306 us) and
 //     slower at 40 x 512 (92 vs 79 us).
 // LDS of the f16 + fp8 form: two 32-channel images + parameters (mt: 128, or 64 = the 12-wave form of the 64-channel tile)
-bool conv_ws_f8_fits(int cin, int pro, int mt) {
-    return ws_smem_bytes(12 * 34, 2, 2, cin, pro, mt, 2, mt == 128 ? 4 : 2, 4, mt == 64 ? 2 * WS64_WST16 : 0) <= (size_t)160 * 1024;
+bool conv_ws_f8_fits(int cin, int pro, int mt, int cout) {
+    return ws_smem_bytes(12 * 34, 2, 2, cin, pro, cout, 2, mt == 128 ? 4 : 2, 4, (GTTS_W64_RING && mt == 64) ? 2 * WS64_WST16 : 0) <= (size_t)160 * 1024;
 }
 bool conv_ws_eligible(int mode, int c0, int c1, int cout, int pro, int epi, int nsplit, int f16f8) {
     const int cin = c0 + c1;
@@ -1224,12 +1226,12 @@ bool conv_ws_eligible(int mode, int c0, int c1, int cout, int pro, int epi, int 
         // 128-channel tiles, or the 64-channel tile (four consumer + eight producer waves)
         if (cout % 128 != 0 && cout != 64) return false;
         if (!conv_f16f8_ok(mode, c0, c1, cout, pro, epi, 1) || cin < 64) return false;
-        return conv_ws_f8_fits(cin, pro, cout == 64 ? 64 : 128);
+        return conv_ws_f8_fits(cin, pro, cout == 64 ? 64 : 128, cout);
     }
     if (cout % 128 != 0) return false;
     if (cin % 16 != 0 || cin < 32 || (c1 != 0 && c0 % 16 != 0)) return false;
     // three activation images + the per-channel parameters must fit the CU's LDS
-    return ws_smem_bytes(12 * 34, 2, 3, cin, pro, 128, 2, 4) <= (size_t)160 * 1024;
+    return ws_smem_bytes(12 * 34, 2, 3, cin, pro, cout, 2, 4) <= (size_t)160 * 1024;
 }
 // GroupNorm partial slots per sample: one per (32-frame column block, 5-row band), whatever the workgroup shape
 int conv_ws_nparts(int cout, int Hout, int Wout) {
@@ -1249,7 +1251,7 @@ bool conv_ws_small(int cout, int groups, int Hout, int Wout, int B, int f16f8) {
     if (groups <= 0 || cout / groups > 32) return false;
     // f16 + fp8, 64 output channels: ONE form at every batch size (its weights are packed by column stage and it accumulates kx-major:
     // the 32-channel small form walks row stages) -- a launch smaller than the chip simply runs fewer 12-wave workgroups
-    if (f16f8 && cout == 64) return false;
+    if (GTTS_W64_RING && f16f8 && cout == 64) return false;
     const long wgs = (long)B * ((Wout + 31) / 32) * ((Hout + 9) / 10) * (cout % 128 == 0 ? cout / 128 : cout / 64);
     return wgs < GTTS_WS_SMALL_WGS;
 }
@@ -1276,7 +1278,7 @@ static hipError_t launch_ws_ring(ConvArgs &a, hipStream_t st) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         n_cu[dev].store(cus, std::memory_order_relaxed);
     }
-    const size_t smem = ws_smem_bytes(C::NPIX, NPL, RING, a.cin, PRO, C::MT, MF, C::NCW, NKG, (NSPLIT == 3 && C::NCWP != C::NCW) ? 2 * WS64_WST16 : 0);
+    const size_t smem = ws_smem_bytes(C::NPIX, NPL, RING, a.cin, PRO, a.cout, MF, C::NCW, NKG, (GTTS_W64_RING && NSPLIT == 3 && C::NCWP != C::NCW) ? 2 * WS64_WST16 : 0);
     if (smem > (size_t)160 * 1024) return hipErrorInvalidValue;      // (conv_ws_eligible keeps such layers on conv_mfma.hip)
     // persistent workgroups: one per CU for the eight-wave form; the three-wave form fits two per CU (registers: 8 waves)
     const int per_cu = C::NT >= 512 ? 1 : (int)std::min<size_t>(2, (size_t)160 * 1024 / smem);

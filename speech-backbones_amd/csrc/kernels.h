@@ -103,8 +103,16 @@ static inline size_t attn_kv_packed_bytes(int C) {      // [head 4][stage][split
     size_t nstage = (C + 16 * ATTN_KCH - 1) / (16 * ATTN_KCH);
     return 4 * nstage * 2 * (2 * ATTN_KCH) * 64 * 16;
 }
+// tail (nullable; C == 64, fp32 storage): the ResnetBlock's identity tail fused into the context pass -- x is then the tail's OUTPUT
+// tensor, which this launch writes: x[c][n] = xin[c][n] * m + Mish(h[c][n] * esc[c] + esh[c]) * m (tail_identity_kernel's arithmetic)
+struct AttnTail {
+    const void *h, *xin;        // raw output of the block's second convolution; the block's input (the residual)
+    const float *esc, *esh;     // [B][C] GroupNorm scale / shift of h
+    const float *mask;          // [B][T]
+    int W, T, lvl;
+};
 hipError_t launch_attn_ctx(const void *x, const unsigned char *wkv, float *partials, int B, int C, int HW, int nsplit,
-                           hipStream_t st, int act_bf16 = 0);
+                           hipStream_t st, int act_bf16 = 0, const AttnTail *tail = nullptr);
 hipError_t launch_attn_merge(const float *partials, float *ctxn, int B, int nrec, hipStream_t st);
 // wq [128][C], wout [C][128], bout [C], g [1] fp32 (reference layouts) -> per-sample packed 1x1 weights + bias
 hipError_t launch_attn_fold(const float *ctxn, const float *wq, const float *wout, const float *bout, const float *g,

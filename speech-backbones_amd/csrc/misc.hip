@@ -236,17 +236,18 @@ __global__ __launch_bounds__(256) void tail_identity_kernel(const AT *__restrict
             const float m0 = mp[(size_t)(col + 0) << lvl], m1 = mp[(size_t)(col + 1) << lvl];
             const float m2 = mp[(size_t)(col + 2) << lvl], m3 = mp[(size_t)(col + 3) << lvl];
             float4 o;
-            o.x = mish_f(hv[it].x * a + s) * m0 + xv[it].x * m0;
-            o.y = mish_f(hv[it].y * a + s) * m1 + xv[it].y * m1;
-            o.z = mish_f(hv[it].z * a + s) * m2 + xv[it].z * m2;
-            o.w = mish_f(hv[it].w * a + s) * m3 + xv[it].w * m3;
+            o.x = tail_value(hv[it].x, xv[it].x, a, s, m0);
+            o.y = tail_value(hv[it].y, xv[it].y, a, s, m1);
+            o.z = tail_value(hv[it].z, xv[it].z, a, s, m2);
+            o.w = tail_value(hv[it].w, xv[it].w, a, s, m3);
             st4(out + plane + i, o);
         }
     } else {
         static_assert(VEC != 1 || ITEMS == 1, "the scalar form takes one item per thread");
         const int col = i0 % W;
         const float m = mask[(size_t)b * T + ((size_t)col << lvl)];
-        out[plane + i0] = (AT)(mish_f((float)h[plane + i0] * a + s) * m + (float)x[plane + i0] * m);
+        if constexpr (sizeof(AT) == 4) out[plane + i0] = (AT)tail_value((float)h[plane + i0], (float)x[plane + i0], a, s, m);
+        else out[plane + i0] = (AT)(mish_f((float)h[plane + i0] * a + s) * m + (float)x[plane + i0] * m);
     }
 }
 

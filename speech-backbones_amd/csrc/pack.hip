@@ -39,7 +39,7 @@ __device__ __forceinline__ void pack_conv_element(const float *__restrict__ w, _
             v = w[(((size_t)ci * cout + co) * 3 + (2 - stage)) * 3 + (2 - tap)];
         } else if (mode == CONV_C7) {
             v = w[(((size_t)co * cin + ci) * 7 + stage) * 7 + tap];          // ky = stage, kx = tap
-        } else if (mode == CONV_C3 && f16f8 && MT == 64) {
+        } else if (GTTS_W64_RING && mode == CONV_C3 && f16f8 && MT == 64) {
             v = w[(((size_t)co * cin + ci) * 3 + tap) * 3 + stage];          // the 64-channel f16 + fp8 tile walks COLUMN stages: kx = stage, ky = tap (conv_ws.hip, W64)
         } else if (mode == CONV_C3 || mode == CONV_DN) {
             v = w[(((size_t)co * cin + ci) * 3 + stage) * 3 + tap];          // ky = stage, kx = tap

@@ -47,6 +47,9 @@ int set_error(int code, const char *msg) { g_err = msg; return code; }     // fo
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct gtts_plan;
 static int plan_nsplit(const gtts_plan *p);      // 2: hi/lo operand planes (BF16X3, and everything F16F8 leaves on it), 1: plain bf16
+#ifndef GTTS_FUSE_TAIL_CTX
+#define GTTS_FUSE_TAIL_CTX 1      // (A/B builds: 0 keeps tail_identity + attn_ctx64 as two launches)
+#endif
 
 // ------------------------------------------------------------------------------------------------ plan data
 enum TensorKind { TK_ACT, TK_PERB, TK_PART, TK_APART, TK_BYTES_PERB, TK_ROWS };
@@ -82,6 +85,8 @@ struct Op {
     int gn_op;                     // EPI_STATS conv: index of the OP_GNFIN it can absorb (-1: none)
     int use_ref;                   // conv / stats run on the reference mel geometry (ref_mask, T_ref)
     int has_tb;                    // PRO_IGLU: a time bias column is added (tb_off valid)
+    int fused;                     // OP_TAILID: done by the following attention context pass (no launch); OP_ACTX: carries that tail
+                                   // (eh / esc / esh = the tail's GroupNorm inputs, eres = the block's input, src0 = the tail's output)
     std::string label;
 };
 
@@ -189,6 +194,7 @@ static Op blank_op(int kind, const std::string &label) {
     o.out = o.part = o.eh = o.esc = o.esh = o.eres = -1; o.C = 0; o.gamma_off = o.beta_off = 0;
     o.wkv_off = o.wq_off = o.wout_off = o.bout_off = o.g_off = 0; o.apart = o.ctxn = -1; o.use_ref = 0; o.has_tb = 0;
     o.gn_op = -1;
+    o.fused = 0;
     o.label = label;
     return o;
 }
@@ -533,6 +539,18 @@ extern "C" int gtts_plan_create(const gtts_unet_cfg *cfg, gtts_plan **out) {
     if (tm.n > 32) { delete p; return fail(GTTS_E_CONFIG, "too many ResnetBlocks"); }
     for (const Op &o : p->ops)
         if (o.kind == OP_CONV && o.c1 > 0 && (o.c0 % 8) != 0) { delete p; return fail(GTTS_E_CONFIG, "concat split must be a multiple of 8 channels"); }
+    // ResnetBlock identity tail -> attention: the 64-channel context kernel applies the tail while it stages (attn.hip), so the tensor
+    // is written once and read once less.  fp32 storage only; wider attentions keep the separate tail (their x tile is staged by two
+    // workgroups, the tail's Mish would run twice).
+    if (p->cfg.precision != GTTS_PREC_BF16_STORE && GTTS_FUSE_TAIL_CTX) {
+        for (size_t i = 0; i + 1 < p->ops.size(); ++i) {
+            Op &t = p->ops[i], &c = p->ops[i + 1];
+            if (t.kind != OP_TAILID || c.kind != OP_ACTX || c.src0 != t.out || !attn_head_per_wave(c.C) || t.C != c.C) continue;
+            t.fused = 1;
+            c.fused = 1;
+            c.eh = t.eh; c.esc = t.esc; c.esh = t.esh; c.eres = t.src0;
+        }
+    }
     compute_liveness(p);
     *out = p;
     return GTTS_OK;
@@ -843,6 +861,7 @@ static int run_ops(const RunCtx &c) {
         const Op &o = p->ops[oi];
         if (o.kind == OP_GNFIN && oi > 0 && p->ops[oi - 1].kind == OP_CONV && p->ops[oi - 1].gn_op == (int)oi && !p->ops[oi - 1].use_ref)
             continue;                               // done by the producing convolution's last workgroup (no launch)
+        if (o.kind == OP_TAILID && o.fused) continue;   // done by the attention context pass that follows (no launch)
         ProfScope prof_scope(p, c.st, (int)oi);
         switch (o.kind) {
             case OP_CONV: {
@@ -906,6 +925,7 @@ static int run_ops(const RunCtx &c) {
                 break;
             }
             case OP_TAILID: {
+                if (o.fused) break;                 // applied by the attention context pass that follows (no launch)
                 const int H = F >> o.lvl_in, W = c.T >> o.lvl_in;
                 hipError_t e = launch_tail_identity(tptr(c, o.eh), tptr(c, o.src0), tptr(c, o.esc), tptr(c, o.esh), c.mask,
                                                     tptr(c, o.out), c.B, o.C, H, W, c.T, o.lvl_in, c.st, abf);
@@ -914,7 +934,13 @@ static int run_ops(const RunCtx &c) {
             }
             case OP_ACTX: {
                 const int HW = (F >> o.lvl_in) * (c.T >> o.lvl_in);
-                hipError_t e = launch_attn_ctx(tptr(c, o.src0), c.blob + o.wkv_off, tptr(c, o.apart), c.B, o.C, HW, nsplit, c.st, abf);
+                AttnTail tl;
+                if (o.fused) {
+                    tl.h = tptr(c, o.eh); tl.xin = tptr(c, o.eres); tl.esc = tptr(c, o.esc); tl.esh = tptr(c, o.esh);
+                    tl.mask = c.mask; tl.W = c.T >> o.lvl_in; tl.T = c.T; tl.lvl = o.lvl_in;
+                }
+                hipError_t e = launch_attn_ctx(tptr(c, o.src0), c.blob + o.wkv_off, tptr(c, o.apart), c.B, o.C, HW, nsplit, c.st, abf,
+                                               o.fused ? &tl : nullptr);
                 if (e != hipSuccess) return fail(GTTS_E_HIP, "attn_ctx %s: %s", o.label.c_str(), hipGetErrorString(e));
                 break;
             }
@@ -1502,20 +1528,22 @@ extern "C" int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, con
                 const int items = (vec > 1 && ((int)(Hi * Wi) / vec + 255) / 256 >= 8) ? 4 : 1;
                 char nb[96];
                 snprintf(nb, sizeof nb, "gtts::tail_identity_kernel<%d, %s, %d>", vec, abf ? "__bf16" : "float", items);
-                s_kernel = nb;
-                by = ab * B * o.C * Hi * Wi * 3;
+                s_kernel = o.fused ? "(fused into the attention context pass)" : nb;
+                by = o.fused ? 0.0 : ab * B * o.C * Hi * Wi * 3;
                 break;
             }
             case OP_ACTX: {
                 char nb[96];
-                if (attn_head_per_wave(o.C))
-                    snprintf(nb, sizeof nb, "gtts::attn_ctx64_kernel<%d, %s>", plan_nsplit(plan), abf ? "__bf16" : "float");
+                if (attn_head_per_wave(o.C) && o.fused)
+                    snprintf(nb, sizeof nb, "gtts::attn_ctx64_kernel<%d, float, 1>", plan_nsplit(plan));
+                else if (attn_head_per_wave(o.C))
+                    snprintf(nb, sizeof nb, "gtts::attn_ctx64_kernel<%d, %s, 0>", plan_nsplit(plan), abf ? "__bf16" : "float");
                 else
                     snprintf(nb, sizeof nb, "gtts::attn_ctx_kernel<%d, %d, %s, %d>", plan_nsplit(plan), o.C % 32 == 0 ? 1 : 0,
                              abf ? "__bf16" : "float", GTTS_ATTN_HPW);
                 s_kernel = nb;
                 fl = 2.0 * B * Hi * Wi * (256.0 * o.C + 128.0 * 32);
-                by = ab * B * o.C * Hi * Wi; break;
+                by = ab * B * o.C * Hi * Wi * (o.fused ? 3 : 1); break;      // (fused tail: block input + raw convolution output in, block output out)
             }
             case OP_AMERGE: s_kernel = "gtts::attn_merge_kernel"; break;
             case OP_INSTATS: s_kernel = "gtts::instnorm_stats_kernel"; by = 4.0 * B * o.C * Hi * Wi; break;
