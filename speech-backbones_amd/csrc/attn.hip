@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void attn_ctx64_kernel(const AttnCtxArgs a)
                     const int c = (it * 4 + wave) * 8 + i;
                     const float v = tail_value(rawh[it][i], raw[it][i], tsc[it][i], tsh[it][i], tmask);
                     raw[it][i] = v;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsx, voff, c * a.HW * 4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsx, voff, c * a.HW * 4, GTTS_OUT_NT);
                 }
         }
     };

@@ -150,10 +150,17 @@ __device__ __forceinline__ float ld_act(__amdgpu_buffer_rsrc_t rs, int voff, int
     if constexpr (sizeof(AT) == 4) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
     else return __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0) << 16);
 }
+// GTTS_OUT_NT: cache policy of the kernels' activation OUTPUT stores -- 2 = nt (streaming: the line is the first to leave the XCD's 4 MB
+// L2, which then keeps the consumer's weights / halo rows instead of output lines no CU of this launch reads again), 0 = plain.
+// Measured (round 6, same box, ms per U-Net call): nt on the persistent convolution's epilogue only (conv_ws.hip, GTTS_WS_EPI_AUX = 2)
+// 6.228-6.234; nt on every kernel's output stores as well (this switch) 6.254-6.256 -> stays 0.
+#ifndef GTTS_OUT_NT
+#define GTTS_OUT_NT 0
+#endif
 template <typename AT>
 __device__ __forceinline__ void st_act(float v, __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
-    if constexpr (sizeof(AT) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs, voff, soff, 0);
-    else __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (__bf16)v), rs, voff, soff, 0);
+    if constexpr (sizeof(AT) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs, voff, soff, GTTS_OUT_NT);
+    else __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (__bf16)v), rs, voff, soff, GTTS_OUT_NT);
 }
 
 // Wave-wide reductions on the DPP path (full-rate VALU, no LDS crossbar): __shfl_xor lowers to ds_bpermute_b32 plus an

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void conv_up4_kernel(const ConvArgs a) {
                 u32x2 v;
                 v[0] = __builtin_bit_cast(unsigned, acc[mi][ni][0][rg] + bv);
                 v[1] = __builtin_bit_cast(unsigned, acc[mi][ni][1][rg] + bv);
-                __builtin_amdgcn_raw_buffer_store_b64(v, rso, voff, (cot * 64 + ch) * HWo * 4, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(v, rso, voff, (cot * 64 + ch) * HWo * 4, GTTS_OUT_NT);
             }
     }
 }

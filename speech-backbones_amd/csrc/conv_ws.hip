@@ -87,11 +87,19 @@ namespace gtts {
 // the 64-channel f16 + fp8 tile (W64): sweep pipelining (0: a sweep reads its A fragments and first B rows itself; 1: the previous sweep
 // prefetches them at input row GTTS_W64_PFROW; 2: A fragments only), B rows fetched GTTS_W64_DIST rows ahead, ring refill after row
 // GTTS_W64_DMAROW (>= 2: every A fragment of the sweep has been consumed by then)
+// cache policy of the f16 + fp8 epilogue's output stores (A/B builds): 0 plain, 2 nt (streaming), 16 sc1 (write-through), 17 sc0 sc1
+#ifndef GTTS_WS_EPI_AUX
+#define GTTS_WS_EPI_AUX 2      // measured (same box, ms per U-Net call): plain 6.432-6.457, nt 6.351, sc1 6.439, sc0 sc1 6.427
+#endif
 #ifndef GTTS_W64_PF
 #define GTTS_W64_PF 0
 #endif
 #ifndef GTTS_W64_DIST
 #define GTTS_W64_DIST 2
+#endif
+// cache policy of the f16 + fp8 epilogue's output stores (A/B builds): 0 plain, 2 nt (streaming), 16 sc1 (write-through), 17 sc0 sc1
+#ifndef GTTS_WS_EPI_AUX
+#define GTTS_WS_EPI_AUX 2      // measured (same box, ms per U-Net call): plain 6.432-6.457, nt 6.351, sc1 6.439, sc0 sc1 6.427
 #endif
 #ifndef GTTS_W64_PFROW
 #define GTTS_W64_PFROW 5
@@ -442,7 +450,10 @@ void conv3x3_ws_kernel(const ConvArgs a) {
                                 }
                                 const int voff = (oy * a.Wout + oxx + 4 * kg_l * HW) * AB;
 #pragma unroll
-                                for (int i = 0; i < 4; ++i) st_act<AT>(v[i], rs_out, voff, soff + i * HW * AB);
+                                for (int i = 0; i < 4; ++i) {
+                                    if constexpr (AB == 4 && GTTS_WS_EPI_AUX != 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v[i]), rs_out, voff, soff + i * HW * AB, GTTS_WS_EPI_AUX);
+                                    else st_act<AT>(v[i], rs_out, voff, soff + i * HW * AB);
+                                }
                             }
                         }
                     }

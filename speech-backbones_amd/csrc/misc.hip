@@ -169,7 +169,14 @@ __device__ __forceinline__ float4 ld4(const __bf16 *p) {
     return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
                        __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
 }
-__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ void st4(float *p, float4 v) {
+    typedef __attribute__((ext_vector_type(4))) float f32x4s;
+    if (GTTS_OUT_NT) {
+        f32x4s q;
+        q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+        __builtin_nontemporal_store(q, reinterpret_cast<f32x4s *>(p));
+    } else *reinterpret_cast<float4 *>(p) = v;
+}
 __device__ __forceinline__ void st4(__bf16 *p, float4 v) {
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
     bf16x4 o;
