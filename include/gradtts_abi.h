@@ -407,6 +407,18 @@ size_t gtts_final_conv_scratch_floats(int B, int C, int H, int W);
 int gtts_final_conv_backward(const float *x, const float *w, const float *mask, const float *dout, float *dx, float *dw, float *db,
                              float *scratch, int B, int C, int H, int W, gtts_stream_t stream);
 
+/* ---- ABI 6: DiffVC decoder training, RefBlock's InstanceNorm2d(affine) + GLU(dim=1) pair (DiffVC/model/modules.py:128-157) ----------
+ * y [B,2C,H,W] (the block's convolution output), gamma / beta [2C]; out [B,C,H,W] = IN(y[:, :C]) * sigmoid(IN(y[:, C:])), statistics
+ * per (sample, channel) plane over H x W (biased variance, eps).  stats: gtts_in_glu_stats_floats(B, C) floats written by the forward
+ * call ((mean, rstd) of both halves) and read by the backward call, which writes dy [B,2C,H,W], dgamma [2C], dbeta [2C];
+ * scratch: gtts_in_glu_scratch_floats(B, C) floats. */
+size_t gtts_in_glu_stats_floats(int B, int C);
+size_t gtts_in_glu_scratch_floats(int B, int C);
+int gtts_in_glu_forward(const float *y, const float *gamma, const float *beta, float *out, float *stats, int B, int C, int H, int W,
+                        float eps, gtts_stream_t stream);
+int gtts_in_glu_backward(const float *dout, const float *y, const float *gamma, const float *beta, const float *stats, float *dy,
+                         float *dgamma, float *dbeta, float *scratch, int B, int C, int H, int W, gtts_stream_t stream);
+
 /* ---- debugging / tests: named intermediates of the last estimator call (keep_intermediates plans) ----- */
 int gtts_plan_num_tensors(const gtts_plan *plan);
 /* offset is in bytes into the workspace for the given (B,T); dims = {B,C,H,W}. */

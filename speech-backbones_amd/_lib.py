@@ -198,6 +198,12 @@ def lib():
         L.gtts_ubench_mfma.argtypes = [vp, sz, vp, i, i, ctypes.POINTER(ctypes.c_double), vp]
         L.gtts_ubench_hbm.argtypes = [vp, vp, vp, sz, i, i, ctypes.POINTER(ctypes.c_double), vp]
         L.gtts_workspace_status.argtypes = [vp, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(f), vp]
+        L.gtts_in_glu_stats_floats.argtypes = [i, i]
+        L.gtts_in_glu_stats_floats.restype = sz
+        L.gtts_in_glu_scratch_floats.argtypes = [i, i]
+        L.gtts_in_glu_scratch_floats.restype = sz
+        L.gtts_in_glu_forward.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, f, vp]
+        L.gtts_in_glu_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, vp]
         if L.gtts_abi_version() != 6:
             raise RuntimeError("libgradtts_gfx950.so ABI version mismatch")
         _lib = L
@@ -1357,6 +1363,34 @@ def gn_mish_backward(dout, y, gamma, beta, mask_cols, stats, groups, want_dtb=Fa
                                               _ptr(_f32c(mask_cols, "mask")), _ptr(stats), _ptr(dy), _ptr(dg), _ptr(db), _ptr(dtb),
                                               _ptr(scratch), B, C, H, W, int(groups), _stream()), "gtts_gn_mish_backward")
     return (dy, dg, db, dtb) if want_dtb else (dy, dg, db)
+
+
+def in_glu_forward(y, gamma, beta, eps=1e-5):
+    """(IN(y[:, :C]) * sigmoid(IN(y[:, C:])), stats) -- InstanceNorm2d(affine) + GLU(dim=1) of DiffVC's RefBlock (modules.py:128-157)."""
+    y, gamma, beta = _f32c(y, "y"), _f32c(gamma, "gamma"), _f32c(beta, "beta")
+    B, C2, H, W = y.shape
+    C = C2 // 2
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=y.device)
+    stats = torch.empty(int(lib().gtts_in_glu_stats_floats(B, C)), dtype=torch.float32, device=y.device)
+    with _on(y.device):
+        _check(lib().gtts_in_glu_forward(_ptr(y), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(stats), B, C, H, W, float(eps), _stream()),
+               "gtts_in_glu_forward")
+    return out, stats
+
+
+def in_glu_backward(dout, y, gamma, beta, stats):
+    """(dy, dgamma, dbeta) of in_glu_forward."""
+    dout, y = _f32c(dout, "dout"), _f32c(y, "y")
+    B, C2, H, W = y.shape
+    C = C2 // 2
+    dy = torch.empty_like(y)
+    dg = torch.empty((C2,), dtype=torch.float32, device=y.device)
+    db = torch.empty((C2,), dtype=torch.float32, device=y.device)
+    scratch = torch.empty(int(lib().gtts_in_glu_scratch_floats(B, C)), dtype=torch.float32, device=y.device)
+    with _on(y.device):
+        _check(lib().gtts_in_glu_backward(_ptr(dout), _ptr(y), _ptr(_f32c(gamma, "gamma")), _ptr(_f32c(beta, "beta")), _ptr(stats),
+                                          _ptr(dy), _ptr(dg), _ptr(db), _ptr(scratch), B, C, H, W, _stream()), "gtts_in_glu_backward")
+    return dy, dg, db
 
 
 def diffusion_noising(x0, mu, z, mask, t, beta_min, beta_max):

@@ -49,15 +49,22 @@ class RefBlock(BaseModule):
     def _block(blk, y, mask):
         """conv3x3(y * mask) -> InstanceNorm -> GLU (DiffVC/model/modules.py:140-157).  Training on the GPU: the convolution (forward, data
         and weight gradient) on the gtts:: training kernels where their tiles allow (64 or a multiple of 128 channels on both sides:
-        block22 / block31 / block32 = 90 % of RefBlock's FLOPs at out_dim 128); InstanceNorm + GLU stay torch ops."""
+        block22 / block31 / block32 = 90 % of RefBlock's FLOPs at out_dim 128; the three narrow layers stay on the framework's
+        convolution), InstanceNorm + GLU of all six blocks on csrc/train_inglu.hip."""
         from ...model import _train_ops as T
         from ...model._backend import backend
-        conv = blk[0]
-        if (torch.is_grad_enabled() and T._hip(y) and y.dim() == 4 and
-                backend().conv3x3_supported(conv.in_channels, conv.out_channels, need_dgrad=True, shape=(y.shape[0], y.shape[2], y.shape[3]))):
+        conv, norm = blk[0], blk[1]
+        if not (torch.is_grad_enabled() and T._hip(y) and y.dim() == 4 and not T.FORCE_TORCH):
+            return blk(y * mask)
+        if backend().conv3x3_supported(conv.in_channels, conv.out_channels, need_dgrad=True, shape=(y.shape[0], y.shape[2], y.shape[3])):
             T._count(True)
-            return blk[2](blk[1](T.MaskedConv3x3.apply(y.contiguous(), mask, conv.weight, conv.bias, None)))
-        return blk(y * mask)
+            h = T.MaskedConv3x3.apply(y.contiguous(), mask, conv.weight, conv.bias, None)
+        else:
+            h = conv(y * mask)
+        if norm.affine and not norm.track_running_stats:
+            T._count(True)
+            return T.InstNormGlu.apply(h.contiguous(), norm.weight, norm.bias, norm.eps)
+        return blk[2](norm(h))
 
     def forward(self, x, mask, time_emb):
         y = self._block(self.block12, self._block(self.block11, x, mask), mask)

@@ -132,6 +132,23 @@ class GnMishMask(torch.autograd.Function):
         return r[0], None, r[1], r[2], None, None, (r[3] if ctx.has_tb else None)
 
 
+class InstNormGlu(torch.autograd.Function):
+    """InstanceNorm2d(affine) -> GLU(dim=1) on a convolution output [B, 2C, H, W] (DiffVC RefBlock, DiffVC/model/modules.py:128-157) with
+    forward and backward on csrc/train_inglu.hip."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, eps):
+        out, stats = backend().in_glu_forward(y, gamma, beta, eps)
+        ctx.save_for_backward(y, gamma, beta, stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, gamma, beta, stats = ctx.saved_tensors
+        dy, dg, db = backend().in_glu_backward(dout.contiguous(), y, gamma, beta, stats)
+        return dy, dg, db, None
+
+
 class MaskedResidualAdd(torch.autograd.Function):
     """h + v * mask (ResnetBlock with an identity res_conv, diffusion.py:77-78; mask None: h + v)."""
 
