@@ -1524,19 +1524,5 @@ def measured_ceilings(device, seconds=2.0):
                     out.setdefault("hbm_detail", {})["%s_%s_wg%d" % (name, "nt" if nt else "plain", wpc)] = round(gbs, 1)
                     best = max(best, gbs)
             out["hbm_%s_gbs" % name] = best
-        # the same copy / read-only sweep over buffers that FIT the 256 MB Infinity Cache (2 x 64 MiB and 2 x 16 MiB): what a
-        # "float4 copy" reaches when the memory-side cache serves it -- the figure a guide quotes for a copy depends on which of the
-        # two regimes its buffers were in (MI355X_MICROARCH.md: 6.29 TB/s; this chip: see hbm_cache_resident)
-        res = {}
-        for mib in (64, 16):
-            ns = mib << 18                              # floats
-            for name, mode in (("copy", 0), ("read", 2)):
-                best = 0.0
-                for nt in (0, 4):
-                    fn = lambda: _check(L.gtts_ubench_hbm(_ptr(a), _ptr(b), _ptr(c), ctypes.c_size_t(ns), mode + nt, cus * 8,
-                                                          ctypes.byref(nbytes), st), "gtts_ubench_hbm")
-                    best = max(best, nbytes.value / timed(fn, 10) * 1e-9)
-                res["%s_%dMiB" % (name, mib)] = round(best, 1)
-        out["hbm_cache_resident"] = res
         out["cus"] = cus
     return out

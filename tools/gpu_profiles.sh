@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-5 evidence on one GPU box visit: the driver's default bench line, rocprofv3 kernel statistics of the headline command (f16f8
+# Per-round evidence on one GPU box visit (tools/gpu_profiles.sh r06): the driver's default bench line, rocprofv3 kernel statistics of the headline command (f16f8
 # default, and the bf16x3 plan of rounds 1-4), of config 4 and of B = 1; HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE in separate
 # kernel-trace-only passes) of config 2 and config 4 in f16f8; the SQ instruction-mix pass; the per-op table.
 # Outputs in gpurun_out/ (copy what is to be judged into profiles/).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
-TAG=${1:-r05}; ROOT=$PWD
+TAG=${1:-r06}; ROOT=$PWD
 timeout 900 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_tables_$TAG.txt; echo "bench rc=$?"; cut -c1-200 gpurun_out/bench_$TAG.json
 stats() { name=$1; shift
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -o prof -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-extras "$@" > /tmp/prof_$name.log 2>&1); echo "rocprof $name rc=$?"
