@@ -55,9 +55,15 @@ __device__ __forceinline__ void pack8_split(const float (&v)[8], u32x4 &hi, u32x
 // the two waves per SIMD of the one-head form.  Measured (B = 16, one stream, alternating repeats on one box): C = 128 at
 // 40 x 512: 117.3 -> 103.8 us; C = 256 at 20 x 256: 58.5 -> 57.8 us (one tile per workgroup: prologue, merge and the launch's
 // tail bound it, not the staging); sampler outputs bit-identical in all three precisions.
-template <int NSPLIT, int FULLC, typename AT = float, int HPW = 1>
+// TAIL = 1 (FULLC, fp32 storage): the ResnetBlock identity tail in front of the attention rides in the staging step, as in
+// attn_ctx64_kernel -- a thread loads the block's input and the raw output of its second convolution for its 8-channel groups,
+// forms x = xin m + Mish(GN(h)) m (common.h::tail_value, bit-identical to tail_identity_kernel) and stages it; the workgroup of the
+// pixel slice's FIRST head group also stores it (the other head groups of the slice recompute the same values from the same -- by
+// then L2-resident -- inputs: the Mish runs 4 / HPW times per element, which is what the separate tail pass's write + re-read cost).
+template <int NSPLIT, int FULLC, typename AT = float, int HPW = 1, int TAIL = 0>
 __global__ __launch_bounds__(256 * HPW, HPW == 1 ? 2 : 1) void attn_ctx_kernel(const AttnCtxArgs a) {
     constexpr int AB = (int)sizeof(AT);
+    static_assert(!TAIL || (FULLC && AB == 4), "the fused tail: whole 32-channel stages, fp32 storage");
     constexpr int KCH = ATTN_KCH, NKG = 2 * KCH;
     constexpr int NKGT = NKG / HPW;                     // channel groups a thread loads and stages per stage
     constexpr int WHEAD = 2 * NKG * 64;                 // 16-byte units of one head's weight stage
@@ -97,9 +103,43 @@ __global__ __launch_bounds__(256 * HPW, HPW == 1 ? 2 : 1) void attn_ctx_kernel(c
     const int xbytes = a.C * a.HW * AB;
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<void *>(((unsigned long long)xhi << 32) | xlo), 0, __builtin_amdgcn_readfirstlane(xbytes), 0x00020000);
+    [[maybe_unused]] float rawh[NKGT][8], tmask = 0.f;
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rsh = rsx, rsi = rsx;
+    [[maybe_unused]] const bool tail_store = (wg % HG) == 0;          // one head group of a pixel slice writes the block's output
+    if constexpr (TAIL) {
+        auto mk = [&](const void *p) {
+            const unsigned long long u = reinterpret_cast<unsigned long long>(reinterpret_cast<const AT *>(p) + (size_t)b * a.C * a.HW);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+            return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0,
+                                                     __builtin_amdgcn_readfirstlane(xbytes), 0x00020000);
+        };
+        rsh = mk(a.tail.h);
+        rsi = mk(a.tail.xin);
+    }
+    // the fused tail of (tile, stage): raw <- the block's output for this thread's channels, stored by the slice's first head group
+    auto apply_tail = [&](int tile, int stage) {
+        if constexpr (TAIL) {
+            const int n = tile * 256 + t255;
+            const int voff = n < a.HW ? n * AB : xbytes;           // (stores beyond the sample are dropped by the bounds check)
+#pragma unroll
+            for (int kg = 0; kg < NKGT; ++kg) {
+                const int cb = stage * 16 * KCH + (hw * NKGT + kg) * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float sc = a.tail.esc[(size_t)b * a.C + cb + i], sh = a.tail.esh[(size_t)b * a.C + cb + i];
+                    const float v = tail_value(rawh[kg][i], raw[kg][i], sc, sh, tmask);
+                    raw[kg][i] = v;
+                    if (tail_store) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsx, voff, (cb + i) * a.HW * 4, GTTS_OUT_NT);
+                }
+            }
+        }
+    };
     auto load = [&](int tile, int stage) {
         const int n = tile * 256 + t255;
         const int voff = n < a.HW ? n * AB : xbytes;
+        if constexpr (TAIL) {
+            if (stage == 0) tmask = n < a.HW ? a.tail.mask[(size_t)b * a.tail.T + ((size_t)(n % a.tail.W) << a.tail.lvl)] : 0.f;
+        }
 #pragma unroll
         for (int kg = 0; kg < NKGT; ++kg) {
             const int cb = stage * 16 * KCH + (hw * NKGT + kg) * 8;
@@ -107,7 +147,10 @@ __global__ __launch_bounds__(256 * HPW, HPW == 1 ? 2 : 1) void attn_ctx_kernel(c
             for (int i = 0; i < 8; ++i) {
                 const int c = FULLC ? cb + i : min(cb + i, a.C - 1);
                 float v;
-                if constexpr (AB == 4) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, voff, c * a.HW * 4, 0));
+                if constexpr (TAIL) {
+                    v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsi, voff, c * a.HW * 4, 0));
+                    rawh[kg][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsh, voff, c * a.HW * 4, 0));
+                } else if constexpr (AB == 4) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, voff, c * a.HW * 4, 0));
                 else v = __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsx, voff, c * a.HW * 2, 0) << 16);
                 raw[kg][i] = (FULLC || cb + i < a.C) ? v : 0.f;
             }
@@ -135,6 +178,7 @@ __global__ __launch_bounds__(256 * HPW, HPW == 1 ? 2 : 1) void attn_ctx_kernel(c
                 for (int r = 0; r < 16; ++r) acc[pf][cf][r] = 0.f;
 
         for (int stage = 0; stage < a.nstage; ++stage) {
+            apply_tail(tile, stage);
             lds_barrier();
 #pragma unroll
             for (int kg = 0; kg < NKGT; ++kg) {
@@ -551,7 +595,7 @@ hipError_t launch_attn_ctx(const void *x, const unsigned char *wkv, float *parti
                            hipStream_t st, int act_bf16, const AttnTail *tail) {
     AttnGeom g = attn_geom(HW, C);
     if ((size_t)C * HW * 4 >= ((size_t)1 << 31)) return hipErrorInvalidValue;     // 32-bit offsets in the buffer descriptor
-    if (tail != nullptr && (!attn_head_per_wave(C) || act_bf16)) return hipErrorInvalidValue;
+    if (tail != nullptr && (C % 32 != 0 || act_bf16)) return hipErrorInvalidValue;
     AttnCtxArgs a;
     memset(&a, 0, sizeof(a));
     if (tail != nullptr) a.tail = *tail;
@@ -579,7 +623,10 @@ hipError_t launch_attn_ctx(const void *x, const unsigned char *wkv, float *parti
         else hipLaunchKernelGGL((attn_ctx_kernel<1, 0, __bf16, HPW>), grid, block, 0, st, a);
         return hipGetLastError();
     }
-    if (C % 32 == 0) {
+    if (C % 32 == 0 && tail != nullptr) {
+        if (nsplit > 1) hipLaunchKernelGGL((attn_ctx_kernel<2, 1, float, HPW, 1>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((attn_ctx_kernel<1, 1, float, HPW, 1>), grid, block, 0, st, a);
+    } else if (C % 32 == 0) {
         if (nsplit > 1) hipLaunchKernelGGL((attn_ctx_kernel<2, 1, float, HPW>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((attn_ctx_kernel<1, 1, float, HPW>), grid, block, 0, st, a);
     } else {

@@ -48,7 +48,9 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 struct gtts_plan;
 static int plan_nsplit(const gtts_plan *p);      // 2: hi/lo operand planes (BF16X3, and everything F16F8 leaves on it), 1: plain bf16
 #ifndef GTTS_FUSE_TAIL_CTX
-#define GTTS_FUSE_TAIL_CTX 1      // (A/B builds: 0 keeps tail_identity + attn_ctx64 as two launches)
+#define GTTS_FUSE_TAIL_CTX 1      // 0: tail_identity + attention context as two launches everywhere; 1: fused for C = 64; 2: for every C % 32 == 0
+                                  // (measured, same box: 2 loses -- the wider attentions stage their x tile in two workgroups, the tail's Mish
+                                  // runs twice in a VALU-bound kernel: tail + context 100 + 104 -> 231 us at level 1, 51 + 59 -> 135 at level 2)
 #endif
 
 // ------------------------------------------------------------------------------------------------ plan data
@@ -545,7 +547,8 @@ extern "C" int gtts_plan_create(const gtts_unet_cfg *cfg, gtts_plan **out) {
     if (p->cfg.precision != GTTS_PREC_BF16_STORE && GTTS_FUSE_TAIL_CTX) {
         for (size_t i = 0; i + 1 < p->ops.size(); ++i) {
             Op &t = p->ops[i], &c = p->ops[i + 1];
-            if (t.kind != OP_TAILID || c.kind != OP_ACTX || c.src0 != t.out || !attn_head_per_wave(c.C) || t.C != c.C) continue;
+            if (t.kind != OP_TAILID || c.kind != OP_ACTX || c.src0 != t.out || t.C != c.C) continue;
+            if (!attn_head_per_wave(c.C) && !(GTTS_FUSE_TAIL_CTX > 1 && c.C % 32 == 0)) continue;
             t.fused = 1;
             c.fused = 1;
             c.eh = t.eh; c.esc = t.esc; c.esh = t.esh; c.eres = t.src0;
@@ -1539,8 +1542,8 @@ extern "C" int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, con
                 else if (attn_head_per_wave(o.C))
                     snprintf(nb, sizeof nb, "gtts::attn_ctx64_kernel<%d, %s, 0>", plan_nsplit(plan), abf ? "__bf16" : "float");
                 else
-                    snprintf(nb, sizeof nb, "gtts::attn_ctx_kernel<%d, %d, %s, %d>", plan_nsplit(plan), o.C % 32 == 0 ? 1 : 0,
-                             abf ? "__bf16" : "float", GTTS_ATTN_HPW);
+                    snprintf(nb, sizeof nb, "gtts::attn_ctx_kernel<%d, %d, %s, %d, %d>", plan_nsplit(plan), o.C % 32 == 0 ? 1 : 0,
+                             abf ? "__bf16" : "float", GTTS_ATTN_HPW, o.fused ? 1 : 0);
                 s_kernel = nb;
                 fl = 2.0 * B * Hi * Wi * (256.0 * o.C + 128.0 * 32);
                 by = ab * B * o.C * Hi * Wi * (o.fused ? 3 : 1); break;      // (fused tail: block input + raw convolution output in, block output out)
