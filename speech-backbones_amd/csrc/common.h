@@ -331,6 +331,11 @@ bool conv_ws_small(int cout, int groups, int Hout, int Wout, int B, int f16f8 = 
 hipError_t launch_conv_ws(const ConvArgs &a, hipStream_t st);
 // conv_up.hip: Upsample with the four output phases computed from one staged tile (fp32 storage, bf16x3)
 bool conv_up4_eligible(const ConvArgs &a);
+// GTTS_PREC_F16F8 plans: Upsample in the f16 + fp8 split (conv_up.hip); decides the packing of the layer's weights as well.  0: bf16x3 (A/B)
+#ifndef GTTS_UP_F16F8
+#define GTTS_UP_F16F8 1
+#endif
+bool conv_up4_f16f8_ok(int cin, int cout);
 hipError_t launch_conv_up4(const ConvArgs &a, hipStream_t st);
 // Block convolutions that take the f16 + fp8 split when the plan's precision is GTTS_PREC_F16F8 (conv_mfma.hip): 3x3, whole
 // 32-channel chunks (a concatenated input splitting on one), mask / GroupNorm prologue, statistics epilogue, and an LDS

@@ -207,6 +207,262 @@ __global__ __launch_bounds__(256, 2) void conv_up4_kernel(const ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ f16 + fp8 form (GTTS_PREC_F16F8)
+// The same tile (64 output channels x 4 input rows x 32 input columns -> 8 x 64 output pixels) in the f16 + fp8 split of common.h:
+// 32-channel chunks, per tap two fp16 k-steps + one fp8 K = 64 step -- 128 MFMA cycles per 32 channels and accumulator against
+// 192 in bf16x3.  EIGHT waves: wave = (output row parity py, input row pair rp, output COLUMN parity px) with accumulators
+// [2 x 32 channels][2 rows] = 4 (64 registers) -- the 16-register weight sets (fp16 k-step 0 / 1 + the fp8 operand) of both column
+// parities do not fit beside eight accumulators; the x tile is still staged once per chunk for all four phases (512 threads).
+// PERSISTENT: one workgroup per CU walks tiles slot, slot + grid, ...  The 64-channel layer has TWO chunks per tile, so a tile-per-
+// workgroup launch never fills its pipeline: measured (round 6, B = 16, T = 1024) 122 us WITHOUT its output stores against 35 us of
+// MFMA time at peak -- every tile pays the first chunk's load latency and its store drain with nothing beside them (one workgroup
+// per CU: 213 registers).  Here the last chunk of a tile issues the next tile's first activation loads and weight fragments, and the
+// epilogue's stores drain under the next tile's staging.
+// Epilogue: the waves of a (py, rp) pair swap half their accumulators through LDS -- wave px = 0 hands over row ni = 1 and takes the
+// partner's row ni = 0 -- so that a lane owns BOTH column parities of one row and stores them as 8 bytes (64 lanes = full lines, as
+// the bf16x3 kernel does; 4-byte stores at stride 8 measured 217 us against 157 on the 64-channel layer).
+// Per-accumulator order: chunk, stage (ky), tap (kx): k-step 0, k-step 1, fp8 -- one form, so results do not depend on the batch.
+#ifndef GTTS_UP_ABL
+#define GTTS_UP_ABL 0
+#endif
+#ifndef GTTS_UP_PERSIST      // 0: one tile per workgroup (A/B)
+#define GTTS_UP_PERSIST 1
+#endif
+constexpr int UP8_ITEMS = 4 * UP_NPIX;                                                // (8-channel group of the 32-channel chunk, pixel)
+constexpr int UP8_LITER = (UP8_ITEMS + 511) / 512;
+
+__global__ __launch_bounds__(512, 1) void conv_up4_f8_kernel(const ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) u32x4 s_img[2][2][4 * UP_NPIX];            // [buffer][fp16 | fp8 plane][kg / g][pixel] (52 KB)
+    __shared__ float s_x[8 * 32 * 64];                                                 // the epilogue's exchange area: [wave][register][lane] (64 KB)
+    __shared__ float s_bias[2][64];                                                    // [tile parity]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kg_l = lane >> 5;
+    const int py = wave & 1, rp = (wave >> 1) & 1, px = wave >> 2;
+
+    const int ncot = a.cout / 64;
+    const int ntiles = a.B * a.tiles_x * a.tiles_y * ncot, G = gridDim.x;
+    const int HW = a.Hin * a.Win, HWo = a.Hout * a.Wout;
+    const int nchunk = a.cin / 32;
+    struct Tile { int cot, b, y0, x0; };
+    auto decode = [&](int t) {
+        Tile r;
+        r.cot = t % ncot; t /= ncot;
+        r.x0 = (t % a.tiles_x) * 32; t /= a.tiles_x;
+        r.y0 = (t % a.tiles_y) * UP_TR;
+        r.b = t / a.tiles_y;
+        return r;
+    };
+
+    auto uniform_rsrc = [](const void *p, int bytes) {
+        const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0,
+                                                 __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+    };
+    const int MTP = a.cout > 64 ? 128 : 64, ncotp = a.cout / MTP, cpp = MTP / 64;
+    const int wblk16 = 16 * MTP;                                 // 16-byte units of one packed block: [fp16: tap 2][kg 4][MTP] [fp8: tap 2][g 4][MTP]
+    const int wtotal = 4 * nchunk * 2 * ncotp * wblk16 * 16;
+    const __amdgpu_buffer_rsrc_t rsw = uniform_rsrc(a.w, wtotal);
+    const int wl_h = (kg_l * MTP + l31) * 16;                    // lane's row in a (tap, kg pair) segment of the fp16 plane
+    const int wl_8 = (kg_l * 2 * MTP + l31) * 16;                // ... of the fp8 plane (g = kg_l * 2 + q)
+    const int phase = py * 2 + px;
+
+    // ---- staging items of this thread: (kg, halo row, halo column) -> 8 channels of one pixel
+    int it_r[UP8_LITER], it_c[UP8_LITER], it_kg[UP8_LITER], it_dst[UP8_LITER];
+#pragma unroll
+    for (int it = 0; it < UP8_LITER; ++it) {
+        const int idx = tid + it * 512;
+        const int kg = min(idx / UP_NPIX, 3), pix = idx - kg * UP_NPIX;
+        it_kg[it] = kg;
+        it_r[it] = pix / UP_HC;
+        it_c[it] = pix - it_r[it] * UP_HC;
+        it_dst[it] = idx < UP8_ITEMS ? pix : -1;
+    }
+    int it_off[UP8_LITER];
+    float it_m[UP8_LITER];
+    __amdgpu_buffer_rsrc_t rsx;
+    auto set_items = [&](const Tile &tl) {
+        rsx = uniform_rsrc(reinterpret_cast<const float *>(a.src0) + (size_t)tl.b * a.cin * HW, a.cin * HW * 4);
+#pragma unroll
+        for (int it = 0; it < UP8_LITER; ++it) {
+            const int gy = tl.y0 - 1 + it_r[it], gx = tl.x0 - 1 + it_c[it];
+            const bool in = it_dst[it] >= 0 && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+            it_off[it] = in ? (gy * a.Win + gx + it_kg[it] * 8 * HW) * 4 : -1;
+            it_m[it] = in ? a.mask[(size_t)tl.b * a.T + ((size_t)gx << a.lvl_in)] : 0.f;
+        }
+    };
+    float raw[UP8_LITER][8];
+    float vmax = 0.f;                       // activation range record (common.h)
+    auto load_chunk = [&](int chunk) {
+        const int soff = chunk * 32 * HW * 4;
+#pragma unroll
+        for (int it = 0; it < UP8_LITER; ++it)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                raw[it][i] = it_off[it] >= 0 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, it_off[it], soff + i * HW * 4, 0)) : 0.f;
+    };
+    auto stage_chunk = [&](int buf) {
+        typedef __attribute__((ext_vector_type(2))) int i32x2;
+#pragma unroll
+        for (int it = 0; it < UP8_LITER; ++it) {
+            if (it_dst[it] < 0) continue;
+            f16x8 fh;
+            int lw[2] = {0, 0}, xw[2] = {0, 0};
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+                const float v0 = mul_mask0(raw[it][i], it_m[it]), v1 = mul_mask0(raw[it][i + 1], it_m[it]);
+                const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+                vmax = f8_range_track(vmax, v0, v1);
+                fh[i] = h0;
+                fh[i + 1] = h1;
+                if (i & 2) f8_cross_pair<true>(v0, v1, h0, h1, lw[i >> 2], xw[i >> 2]);
+                else f8_cross_pair<false>(v0, v1, h0, h1, lw[i >> 2], xw[i >> 2]);
+            }
+            const int kg = it_kg[it], pix = it_dst[it];
+            s_img[buf][0][kg * UP_NPIX + pix] = __builtin_bit_cast(u32x4, fh);
+            // fp8 plane: [g = term * 2 + (kg >> 1)][pixel][16 bytes]; this item owns bytes 8 (kg & 1) .. + 7 of its pixel
+            i32x2 *d8 = reinterpret_cast<i32x2 *>(&s_img[buf][1][0]);
+            i32x2 q0, q1;
+            q0[0] = lw[0]; q0[1] = lw[1];
+            q1[0] = xw[0]; q1[1] = xw[1];
+            d8[((kg >> 1) * UP_NPIX + pix) * 2 + (kg & 1)] = q0;
+            d8[((2 + (kg >> 1)) * UP_NPIX + pix) * 2 + (kg & 1)] = q1;
+        }
+    };
+
+    struct W8Set { f16x8 a[2], b[2]; i32x8 w8[2]; };      // [mi]
+    auto wload = [&](W8Set &w, int cot, int chunk, int stage, int tap) {
+        const int blk = ((phase * nchunk + chunk) * 2 + stage) * ncotp + cot / cpp;
+        const int so = blk * (wblk16 * 16) + (cot % cpp) * 64 * 16;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const u32x4 va = __builtin_amdgcn_raw_buffer_load_b128(rsw, wl_h + mi * 32 * 16, so + ((tap * 4) * MTP) * 16, 0);
+            const u32x4 vb = __builtin_amdgcn_raw_buffer_load_b128(rsw, wl_h + mi * 32 * 16, so + ((tap * 4 + 2) * MTP) * 16, 0);
+            const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rsw, wl_8 + mi * 32 * 16, so + (((2 + tap) * 4) * MTP) * 16, 0);
+            const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rsw, wl_8 + mi * 32 * 16, so + (((2 + tap) * 4 + 1) * MTP) * 16, 0);
+            w.a[mi] = __builtin_bit_cast(f16x8, va);
+            w.b[mi] = __builtin_bit_cast(f16x8, vb);
+            w.w8[mi][0] = (int)q0[0]; w.w8[mi][1] = (int)q0[1]; w.w8[mi][2] = (int)q0[2]; w.w8[mi][3] = (int)q0[3];
+            w.w8[mi][4] = (int)q1[0]; w.w8[mi][5] = (int)q1[1]; w.w8[mi][6] = (int)q1[2]; w.w8[mi][7] = (int)q1[3];
+        }
+    };
+
+    f32x16 acc[2][2];      // [mi][row]
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    };
+    zero_acc();
+
+    int tile = xcd_slot(blockIdx.x, G), par = 0;
+    Tile cur = decode(tile);
+    W8Set wset[2];      // (four taps per chunk: the parity of a tap's set is the same in every chunk)
+    set_items(cur);
+    load_chunk(0);
+    wload(wset[0], cur.cot, 0, 0, 0);
+    while (true) {
+        const bool more = tile + G < ntiles;
+        const Tile nx = decode(more ? tile + G : tile);
+        if (tid < 64) s_bias[par][tid] = a.bias[cur.cot * 64 + tid];
+        for (int chunk = 0; chunk < nchunk; ++chunk) {
+            const int buf = chunk & 1;
+            const bool lastc = chunk + 1 == nchunk;
+            stage_chunk(buf);
+            if (!lastc) load_chunk(chunk + 1);
+            else if (more) { set_items(nx); load_chunk(0); }      // the next tile's first chunk rides under this tile's last MFMAs and its epilogue
+            lds_barrier();
+            const u32x4 *xh_p = &s_img[buf][0][kg_l * UP_NPIX];                  // fp16 plane, k-step 0 (k-step 1: + 2 NPIX)
+            const u32x4 *x8_p = &s_img[buf][1][kg_l * 2 * UP_NPIX];              // fp8 plane: g = 2 kg_l (second half: + NPIX)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const int dyr = py == 0 ? (st == 0 ? 0 : -1) : (st == 0 ? 1 : 0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    // next tap's weights (the last tap of a chunk asks for the next chunk's -- or the next tile's -- first; past the end: unused)
+                    const bool last = st == 1 && j == 1;
+                    W8Set &wc = wset[j], &wn = wset[j ^ 1];
+                    wload(wn, (last && lastc) ? nx.cot : cur.cot, last ? (lastc ? 0 : chunk + 1) : chunk, last ? 0 : (j == 1 ? st + 1 : st),
+                          last ? 0 : (j == 1 ? 0 : 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int dxc = px == 0 ? (j == 0 ? 0 : -1) : (j == 0 ? 1 : 0);
+                    f16x8 fa[2], fb[2];
+                    i32x8 b8[2];
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        const int pi = (rp * 2 + ni + 1 + dyr) * UP_HC + 1 + dxc + l31;
+                        fa[ni] = __builtin_bit_cast(f16x8, xh_p[pi]);
+                        fb[ni] = __builtin_bit_cast(f16x8, xh_p[2 * UP_NPIX + pi]);
+                        const u32x4 q0 = x8_p[pi], q1 = x8_p[UP_NPIX + pi];
+                        b8[ni][0] = (int)q0[0]; b8[ni][1] = (int)q0[1]; b8[ni][2] = (int)q0[2]; b8[ni][3] = (int)q0[3];
+                        b8[ni][4] = (int)q1[0]; b8[ni][5] = (int)q1[1]; b8[ni][6] = (int)q1[2]; b8[ni][7] = (int)q1[3];
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc.a[mi], fa[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc.b[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wc.w8[mi], b8[ni], acc[mi][ni], 0, 0, 0, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+
+        // ---- epilogue: half exchange, then acc 2^-S + bias as 8-byte stores.  (The exchange area is this tile's alone until the next
+        // tile's first chunk barrier; the barrier below also says that every wave is done with the images.)
+        {
+            float *mine = s_x + ((wave & 3) * 2 + px) * (32 * 64) + lane;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) mine[(mi * 16 + rg) * 64] = px ? acc[mi][0][rg] : acc[mi][1][rg];
+        }
+        lds_barrier();
+        const __amdgpu_buffer_rsrc_t rso = uniform_rsrc(reinterpret_cast<float *>(a.out) + (size_t)cur.b * a.cout * HWo, a.cout * HWo * 4);
+        const int ix = cur.x0 + l31;
+        const int iy = cur.y0 + rp * 2 + px;                 // this wave stores row ni = px
+        if (iy < a.Hin && ix < a.Win) {
+            typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+            const float *theirs = s_x + ((wave & 3) * 2 + (px ^ 1)) * (32 * 64) + lane;
+            const int oy = 2 * iy + py;
+            const int voff = (oy * a.Wout + 2 * ix + 4 * kg_l * HWo) * 4;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int ch = mi * 32 + (rg & 3) + 8 * (rg >> 2);          // (+ 4 kg_l: in voff)
+                    const float bv = s_bias[par][ch + 4 * kg_l];
+                    const float own = fmaf(px ? acc[mi][1][rg] : acc[mi][0][rg], 1.0f / (float)(1 << F8_S), bv);
+                    const float oth = fmaf(theirs[(mi * 16 + rg) * 64], 1.0f / (float)(1 << F8_S), bv);
+                    u32x2 v;
+                    v[0] = __builtin_bit_cast(unsigned, px ? oth : own);
+                    v[1] = __builtin_bit_cast(unsigned, px ? own : oth);
+#if GTTS_UP_ABL == 1      // timing ablation: no output stores
+                    if (own != 12345.678f) continue;
+#endif
+                    __builtin_amdgcn_raw_buffer_store_b64(v, rso, voff, (cur.cot * 64 + ch) * HWo * 4, GTTS_OUT_NT);
+                }
+        }
+        if (!more) break;
+        zero_acc();
+        tile += G;
+        cur = nx;
+        par ^= 1;
+    }
+    f8_range_note(a.sat, vmax);
+}
+
 // The layers this kernel takes: Upsample of the training / sampling path in fp32 storage and bf16x3, whole 16-channel chunks,
 // whole 64-channel output tiles, shared (not per-sample) weights.
 bool conv_up4_eligible(const ConvArgs &a) {
@@ -216,6 +472,11 @@ bool conv_up4_eligible(const ConvArgs &a) {
            (size_t)a.cout * a.Hout * a.Wout * 4 < ((size_t)1 << 31);
 }
 
+// GTTS_PREC_F16F8: Upsample layers whose weights the plan packs in the f16 + fp8 format (whole 32-channel chunks)
+bool conv_up4_f16f8_ok(int cin, int cout) {
+    return GTTS_UP_F16F8 && cin % 32 == 0 && cin >= 32 && cout % 64 == 0 && (cout <= 64 || cout % 128 == 0);
+}
+
 hipError_t launch_conv_up4(const ConvArgs &a_in, hipStream_t st) {
     ConvArgs a = a_in;
     if (!conv_up4_eligible(a)) return hipErrorInvalidValue;
@@ -223,7 +484,20 @@ hipError_t launch_conv_up4(const ConvArgs &a_in, hipStream_t st) {
     a.tiles_y = (a.Hin + UP_TR - 1) / UP_TR;
     const long grid = (long)a.B * a.tiles_x * a.tiles_y * (a.cout / 64);
     if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(conv_up4_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
+    if (a.f16f8 && conv_up4_f16f8_ok(a.cin, a.cout)) {
+        // persistent: one workgroup per CU (213 registers x 8 waves)
+        static std::atomic<int> n_cu[64];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        int cus = n_cu[dev].load(std::memory_order_relaxed);
+        if (cus == 0) {
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            n_cu[dev].store(cus, std::memory_order_relaxed);
+        }
+        hipLaunchKernelGGL(conv_up4_f8_kernel, dim3((unsigned)std::min<long>(grid, GTTS_UP_PERSIST ? cus : grid)), dim3(512), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(conv_up4_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
+    }
     return hipGetLastError();
 }
 

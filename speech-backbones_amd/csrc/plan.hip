@@ -97,7 +97,8 @@ struct ParamDesc {
     int rank;
     int dims[4];
     size_t off;      // blob byte offset of the packed / copied form
-    int pack;        // 0 copy fp32, 1 conv C3, 2 conv DN, 3 conv UP, 4 conv P1, 5 to_qkv (kv packed + q copy), 6 conv C3 in the f16 + fp8 format
+    int pack;        // 0 copy fp32, 1 conv C3, 2 conv DN, 3 conv UP, 4 conv P1, 5 to_qkv (kv packed + q copy), 6 conv C3 in the f16 + fp8 format,
+                     // 7 conv UP in the f16 + fp8 format
     size_t off2;     // to_qkv: fp32 copy of the q rows
     int cin, cout;
 };
@@ -166,7 +167,7 @@ static int add_param(gtts_plan *p, const std::string &name, std::vector<int> dim
         case 0: bytes = n * 4; break;
         case 1: case 6: bytes = conv_packed_bytes(CONV_C3, cin, cout); break;      // (6: cin % 32 == 0, the same bytes in 32-channel chunks)
         case 2: bytes = conv_packed_bytes(CONV_DN, cin, cout); break;
-        case 3: bytes = conv_packed_bytes(CONV_UP, cin, cout); break;
+        case 3: case 7: bytes = conv_packed_bytes(CONV_UP, cin, cout); break;      // (7: the same bytes in 32-channel chunks, f16 + fp8 format)
         case 4: bytes = conv_packed_bytes(CONV_P1, cin, cout); break;
         case 5: bytes = attn_kv_packed_bytes(cin); break;
     }
@@ -307,7 +308,7 @@ static int add_attn(gtts_plan *p, const std::string &name, int src, int C, int l
 static int add_resample(gtts_plan *p, const std::string &name, int src, int C, int lvl, bool down) {
     const std::string pre = name + ".";
     if (down) add_param(p, pre + "conv.weight", {C, C, 3, 3}, 2, C, C);
-    else add_param(p, pre + "conv.weight", {C, C, 4, 4}, 3, C, C);
+    else add_param(p, pre + "conv.weight", {C, C, 4, 4}, (p->cfg.precision == GTTS_PREC_F16F8 && conv_up4_f16f8_ok(C, C)) ? 7 : 3, C, C);
     add_param(p, pre + "conv.bias", {C}, 0);
     const int lvl_out = down ? lvl + 1 : lvl - 1;
     const int out = add_tensor(p, name + ".out", TK_ACT, C, lvl_out);
@@ -661,6 +662,7 @@ extern "C" int gtts_pack_weights(const gtts_plan *plan, const void *const *param
             case 1: HIPCHK(launch_pack_conv(CONV_C3, src, blob + d.off, d.cin, d.cout, st)); break;
             case 2: HIPCHK(launch_pack_conv(CONV_DN, src, blob + d.off, d.cin, d.cout, st)); break;
             case 3: HIPCHK(launch_pack_conv(CONV_UP, src, blob + d.off, d.cin, d.cout, st)); break;
+            case 7: HIPCHK(launch_pack_conv(CONV_UP | 32, src, blob + d.off, d.cin, d.cout, st, (unsigned *)(blob + plan->status_off), (unsigned)i)); break;
             case 4: HIPCHK(launch_pack_conv(CONV_P1, src, blob + d.off, d.cin, d.cout, st)); break;
             case 6: HIPCHK(launch_pack_conv(CONV_C3 | 32, src, blob + d.off, d.cin, d.cout, st, (unsigned *)(blob + plan->status_off), (unsigned)i)); break;
             case 5:
@@ -1455,7 +1457,7 @@ extern "C" int gtts_log_prior(const float *mu_x, const float *y, float *log_prio
 // ------------------------------------------------------------------------------------------------ measurement
 // the template instance launch_conv picks (conv_mfma.hip: launch_prec / launch_cfg), as rocprofv3 prints it
 static std::string conv_kernel_name(int mode, int cin, int cout, int pro, int epi, int nsplit, bool abf, bool small, bool ws, int B, int Ho,
-                                    int Wo, int groups, bool f8 = false) {
+                                    int Wo, int groups, bool f8 = false, bool up_f8 = false) {
     const bool wide = cout > 64;
     if (ws) {      // conv_ws.hip (launch_ws_pro)
         char wb[128];
@@ -1465,7 +1467,8 @@ static std::string conv_kernel_name(int mode, int cin, int cout, int pro, int ep
                  abf ? "__bf16" : "float", f8 ? 2 : 3);
         return wb;
     }
-    if (mode == CONV_UP && nsplit == 2 && !abf && cin % 16 == 0 && pro == PRO_MASK && epi == EPI_PLAIN) return "gtts::conv_up4_kernel";   // conv_up.hip
+    if (mode == CONV_UP && nsplit == 2 && !abf && cin % 16 == 0 && pro == PRO_MASK && epi == EPI_PLAIN)      // conv_up.hip
+        return (up_f8 && conv_up4_f16f8_ok(cin, cout)) ? "gtts::conv_up4_f8_kernel" : "gtts::conv_up4_kernel";
     const int kch = conv_geom(mode, cin, cout, f8 ? 1 : 0).kch;
     if (f8) nsplit = 3;
     const bool fullc = cin % 16 == 0;
@@ -1521,7 +1524,8 @@ extern "C" int gtts_plan_op_info(const gtts_plan *plan, int i, int B, int T, con
                                             plan->cfg.precision == GTTS_PREC_BF16_STORE, conv_small_tiles(o.mode, o.cout, Ho, Wo, B),
                                             plan->cfg.conv_ws && conv_ws_eligible(o.mode, o.c0, o.c1, o.cout, o.pro, o.epi, plan_nsplit(plan), plan->cfg.precision == GTTS_PREC_F16F8),
                                             B, (int)Ho, (int)Wo, plan->cfg.groups,
-                                            plan->cfg.precision == GTTS_PREC_F16F8 && conv_f16f8_ok(o.mode, o.c0, o.c1, o.cout, o.pro, o.epi, plan->cfg.conv_ws));
+                                            plan->cfg.precision == GTTS_PREC_F16F8 && conv_f16f8_ok(o.mode, o.c0, o.c1, o.cout, o.pro, o.epi, plan->cfg.conv_ws),
+                                            plan->cfg.precision == GTTS_PREC_F16F8);
                 break;
             }
             case OP_GNFIN: s_kernel = "gtts::gn_finalize_kernel"; break;
