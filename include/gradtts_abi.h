@@ -56,10 +56,10 @@ enum {
                                 activation tensor of the U-Net stored as bf16 (weights are bf16 already); GroupNorm
                                 statistics come from the fp32 accumulators before rounding.  Grad-TTS plans only. */
     GTTS_PREC_F16F8 = 3      /* ABI 5.  fp32-grade like BF16X3 (~2^-17 per product), two MFMA pass-equivalents instead of three
-                                on the 3x3 Block convolutions: x = fp16 hi + residual; hi*hi on the fp16 MFMA, both cross terms
+                                on the 3x3 Block convolutions and the Upsample transposed convolutions: x = fp16 hi + residual; hi*hi on the fp16 MFMA, both cross terms
                                 (w * x_lo + w_lo * x, operands rounded to fp8 e4m3) in ONE fp8 MFMA per 32 channels.  Every other
-                                contraction of the plan (1x1, resampling, attention, the 2-channel first layer) stays BF16X3.
-                                RANGE CONTRACT (ABI 6, enforced): 3x3 Block-convolution weights must satisfy |w| < 63.97 (w 2^10
+                                contraction of the plan (1x1, Downsample, attention, the 2-channel first layer) stays BF16X3.
+                                RANGE CONTRACT (ABI 6, enforced): the weights of those layers must satisfy |w| < 63.97 (w 2^10
                                 in fp16) -- gtts_pack_weights checks every such weight on the device and returns GTTS_E_RANGE
                                 naming a layer (nothing is ever packed as inf); an activation with |x| >= 1024 keeps an
                                 fp16-grade cross term only (its fp8 operand saturates; beyond 65504 the fp16 half overflows) --

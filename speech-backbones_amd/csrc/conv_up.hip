@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void conv_up4_kernel(const ConvArgs a) {
 // 192 in bf16x3.  EIGHT waves: wave = (output row parity py, input row pair rp, output COLUMN parity px) with accumulators
 // [2 x 32 channels][2 rows] = 4 (64 registers) -- the 16-register weight sets (fp16 k-step 0 / 1 + the fp8 operand) of both column
 // parities do not fit beside eight accumulators; the x tile is still staged once per chunk for all four phases (512 threads).
-// PERSISTENT: one workgroup per CU walks tiles slot, slot + grid, ...  The 64-channel layer has TWO chunks per tile, so a tile-per-
+// PERSISTENT: the workgroups a CU holds (template parameter NRP below) walk tiles slot, slot + grid, ...  The 64-channel layer has TWO chunks per tile, so a tile-per-
 // workgroup launch never fills its pipeline: measured (round 6, B = 16, T = 1024) 122 us WITHOUT its output stores against 35 us of
 // MFMA time at peak -- every tile pays the first chunk's load latency and its store drain with nothing beside them (one workgroup
 // per CU: 213 registers).  Here the last chunk of a tile issues the next tile's first activation loads and weight fragments, and the
@@ -225,19 +225,26 @@ __global__ __launch_bounds__(256, 2) void conv_up4_kernel(const ConvArgs a) {
 #ifndef GTTS_UP_ABL
 #define GTTS_UP_ABL 0
 #endif
+#ifndef GTTS_UP_NRP
+#define GTTS_UP_NRP 1
+#endif
 #ifndef GTTS_UP_PERSIST      // 0: one tile per workgroup (A/B)
 #define GTTS_UP_PERSIST 1
 #endif
-constexpr int UP8_ITEMS = 4 * UP_NPIX;                                                // (8-channel group of the 32-channel chunk, pixel)
-constexpr int UP8_LITER = (UP8_ITEMS + 511) / 512;
-
-__global__ __launch_bounds__(512, 1) void conv_up4_f8_kernel(const ConvArgs a) {
-    __shared__ __attribute__((aligned(16))) u32x4 s_img[2][2][4 * UP_NPIX];            // [buffer][fp16 | fp8 plane][kg / g][pixel] (52 KB)
-    __shared__ float s_x[8 * 32 * 64];                                                 // the epilogue's exchange area: [wave][register][lane] (64 KB)
+// NRP: input row pairs of a tile.  2: the eight-wave workgroup above, one per CU.  1: FOUR waves (py, px) on a 2-row tile, TWO workgroups
+// per CU (67 KB of LDS, 244 registers): a third more staging per MFMA (4 halo rows for 2); one workgroup's store burst can run beside
+// the other's MFMAs.  Measured equal within noise (113 / 149 us against 112 / 154 on one box; bf16x3 122 / 152); the product uses 1.
+template <int NRP>
+__global__ __launch_bounds__(256 * NRP, 2) void conv_up4_f8_kernel(const ConvArgs a) {
+    constexpr int UP_TR = 2 * NRP, UP_NPIX = (UP_TR + 2) * UP_HC, NT = 256 * NRP, NWV = 4 * NRP;
+    constexpr int UP8_ITEMS = 4 * UP_NPIX;                                             // (8-channel group of the 32-channel chunk, pixel)
+    constexpr int UP8_LITER = (UP8_ITEMS + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) u32x4 s_img[2][2][4 * UP_NPIX];            // [buffer][fp16 | fp8 plane][kg / g][pixel] (52 / 35 KB)
+    __shared__ float s_x[NWV * 32 * 64];                                               // the epilogue's exchange area: [wave][register][lane] (64 / 32 KB)
     __shared__ float s_bias[2][64];                                                    // [tile parity]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kg_l = lane >> 5;
-    const int py = wave & 1, rp = (wave >> 1) & 1, px = wave >> 2;
+    const int py = wave & 1, rp = NRP == 2 ? (wave >> 1) & 1 : 0, px = wave >> NRP;
 
     const int ncot = a.cout / 64;
     const int ntiles = a.B * a.tiles_x * a.tiles_y * ncot, G = gridDim.x;
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(512, 1) void conv_up4_f8_kernel(const ConvArgs a) {
     int it_r[UP8_LITER], it_c[UP8_LITER], it_kg[UP8_LITER], it_dst[UP8_LITER];
 #pragma unroll
     for (int it = 0; it < UP8_LITER; ++it) {
-        const int idx = tid + it * 512;
+        const int idx = tid + it * NT;
         const int kg = min(idx / UP_NPIX, 3), pix = idx - kg * UP_NPIX;
         it_kg[it] = kg;
         it_r[it] = pix / UP_HC;
@@ -422,7 +429,7 @@ __global__ __launch_bounds__(512, 1) void conv_up4_f8_kernel(const ConvArgs a) {
         // ---- epilogue: half exchange, then acc 2^-S + bias as 8-byte stores.  (The exchange area is this tile's alone until the next
         // tile's first chunk barrier; the barrier below also says that every wave is done with the images.)
         {
-            float *mine = s_x + ((wave & 3) * 2 + px) * (32 * 64) + lane;
+            float *mine = s_x + ((wave & (2 * NRP - 1)) * 2 + px) * (32 * 64) + lane;
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -434,7 +441,7 @@ __global__ __launch_bounds__(512, 1) void conv_up4_f8_kernel(const ConvArgs a) {
         const int iy = cur.y0 + rp * 2 + px;                 // this wave stores row ni = px
         if (iy < a.Hin && ix < a.Win) {
             typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-            const float *theirs = s_x + ((wave & 3) * 2 + (px ^ 1)) * (32 * 64) + lane;
+            const float *theirs = s_x + ((wave & (2 * NRP - 1)) * 2 + (px ^ 1)) * (32 * 64) + lane;
             const int oy = 2 * iy + py;
             const int voff = (oy * a.Wout + 2 * ix + 4 * kg_l * HWo) * 4;
 #pragma unroll
@@ -485,7 +492,11 @@ hipError_t launch_conv_up4(const ConvArgs &a_in, hipStream_t st) {
     const long grid = (long)a.B * a.tiles_x * a.tiles_y * (a.cout / 64);
     if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
     if (a.f16f8 && conv_up4_f16f8_ok(a.cin, a.cout)) {
-        // persistent: one workgroup per CU (213 registers x 8 waves)
+        // persistent: GTTS_UP_NRP = 2: one eight-wave workgroup per CU; 1: two four-wave workgroups per CU on 2-row tiles
+        constexpr int NRP = GTTS_UP_NRP;
+        a.tiles_y = (a.Hin + 2 * NRP - 1) / (2 * NRP);
+        const long tiles = (long)a.B * a.tiles_x * a.tiles_y * (a.cout / 64);
+        if (tiles > 0x7fffffffL) return hipErrorInvalidValue;
         static std::atomic<int> n_cu[64];
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -494,7 +505,7 @@ hipError_t launch_conv_up4(const ConvArgs &a_in, hipStream_t st) {
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
             n_cu[dev].store(cus, std::memory_order_relaxed);
         }
-        hipLaunchKernelGGL(conv_up4_f8_kernel, dim3((unsigned)std::min<long>(grid, GTTS_UP_PERSIST ? cus : grid)), dim3(512), 0, st, a);
+        hipLaunchKernelGGL(conv_up4_f8_kernel<NRP>, dim3((unsigned)std::min<long>(tiles, GTTS_UP_PERSIST ? cus * (3 - NRP) : tiles)), dim3(256 * NRP), 0, st, a);
     } else {
         hipLaunchKernelGGL(conv_up4_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
     }

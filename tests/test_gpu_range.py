@@ -2,7 +2,7 @@
 
 The reference arithmetic is plain fp32 (Grad-TTS/model/diffusion.py:49-58): any weight, any activation.  The f16 + fp8 split has
 two limits, and neither may be silent:
-  (a) a 3x3 Block-convolution weight with |w| >= 63.97 does not fit fp16(w 2^10): gtts_pack_weights checks on the device and returns
+  (a) a 3x3 Block-convolution (or Upsample) weight with |w| >= 63.97 does not fit fp16(w 2^10): gtts_pack_weights checks on the device and returns
       GTTS_E_RANGE (nothing is packed as inf); the drop-in module then samples in bf16x3 and warns;
   (b) an activation with |x| >= 1024 keeps only an fp16-grade cross term: the staging kernels count such events and the maximum |x|
       into the first 16 bytes of the workspace, read with gtts_workspace_status / Plan.range_status / GradLogPEstimator2d.range_status.
@@ -54,6 +54,17 @@ def test_pack_refuses_out_of_range_weights(S, dev, value):
     S.Plan(precision=S.PREC_F16F8).pack(_big_weight_state(63.9), dev)
     # a layer the split does not touch (1x1 res_conv: bf16x3 in every precision) may hold anything
     S.Plan(precision=S.PREC_F16F8).pack(_big_weight_state(500.0, "downs.1.0.res_conv.weight"), dev)
+
+
+def test_pack_refuses_out_of_range_upsample_weight(S, dev):
+    """The Upsample layers take the split as well (conv_up.hip): same check, the message names the layer."""
+    sd = _big_weight_state(-80.0, "ups.0.3.conv.weight")
+    with pytest.raises(S.RangeError) as ei:
+        S.Plan(precision=S.PREC_F16F8).pack(sd, dev)
+    assert "ups.0.3.conv.weight" in str(ei.value), str(ei.value)
+    S.Plan(precision=S.PREC_F16F8).pack(_big_weight_state(-63.9, "ups.0.3.conv.weight"), dev)
+    # Downsample stays bf16x3
+    S.Plan(precision=S.PREC_F16F8).pack(_big_weight_state(500.0, "downs.0.3.conv.weight"), dev)
 
 
 def test_weight_at_the_edge_is_exact_enough(S, dev):
