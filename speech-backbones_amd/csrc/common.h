@@ -336,6 +336,7 @@ bool conv_up4_eligible(const ConvArgs &a);
 #define GTTS_UP_F16F8 1
 #endif
 bool conv_up4_f16f8_ok(int cin, int cout);
+const char *conv_up4_f8_name();      // the instance launch_conv_up4 launches for such layers (per-op tables)
 hipError_t launch_conv_up4(const ConvArgs &a, hipStream_t st);
 // Block convolutions that take the f16 + fp8 split when the plan's precision is GTTS_PREC_F16F8 (conv_mfma.hip): 3x3, whole
 // 32-channel chunks (a concatenated input splitting on one), mask / GroupNorm prologue, statistics epilogue, and an LDS

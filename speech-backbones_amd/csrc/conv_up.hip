@@ -484,6 +484,8 @@ bool conv_up4_f16f8_ok(int cin, int cout) {
     return GTTS_UP_F16F8 && cin % 32 == 0 && cin >= 32 && cout % 64 == 0 && (cout <= 64 || cout % 128 == 0);
 }
 
+const char *conv_up4_f8_name() { return GTTS_UP_NRP == 1 ? "gtts::conv_up4_f8_kernel<1>" : "gtts::conv_up4_f8_kernel<2>"; }
+
 hipError_t launch_conv_up4(const ConvArgs &a_in, hipStream_t st) {
     ConvArgs a = a_in;
     if (!conv_up4_eligible(a)) return hipErrorInvalidValue;
