@@ -1165,6 +1165,8 @@ hipError_t launch_conv(int mode, const ConvArgs &a, hipStream_t st) {
         case CONV_UP:
             if (a.pro != PRO_MASK || a.epi != EPI_PLAIN) break;
             if (conv_up4_eligible(a)) return launch_conv_up4(a, st);
+            // a GTTS_PREC_F16F8 plan packed this layer's weights in the f16 + fp8 format: only conv_up.hip reads it -- fail, never misread
+            if (a.f16f8 && conv_up4_f16f8_ok(a.cin, a.cout)) return hipErrorInvalidValue;
             return wide ? launch_prec<CONV_UP, 2, 2, 2, PRO_MASK, EPI_PLAIN>(a, st)
                         : launch_prec<CONV_UP, 1, 4, 2, PRO_MASK, EPI_PLAIN>(a, st);
         case CONV_P1:

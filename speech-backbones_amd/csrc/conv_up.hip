@@ -222,7 +222,12 @@ __global__ __launch_bounds__(256, 2) void conv_up4_kernel(const ConvArgs a) {
 // partner's row ni = 0 -- so that a lane owns BOTH column parities of one row and stores them as 8 bytes (64 lanes = full lines, as
 // the bf16x3 kernel does; 4-byte stores at stride 8 measured 217 us against 157 on the 64-channel layer).
 // Per-accumulator order: chunk, stage (ky), tap (kx): k-step 0, k-step 1, fp8 -- one form, so results do not depend on the batch.
-#ifndef GTTS_UP_ABL
+// Where the time goes (GTTS_UP_ABL builds, us per launch, 128- / 64-channel layer, one box): as built 111.6 / 152; no output stores
+// 106.5 / 121; no activation loads 81 / 98; neither 77 / 87.  The 84 MB of input cost 54 us on the 64-channel layer: latency, not
+// bandwidth -- a wave's loads return in order, so the wait for the NEXT TAP's weight fragments (L2 hits, issued after the next chunk's
+// activation loads) is a wait for those HBM loads as well, once per chunk, whatever the prefetch distance in chunks.  Taking the
+// activation loads out of the MFMA waves' queue needs producer waves, i.e. the MFMA waves in 168 registers (they use 213-244).
+#ifndef GTTS_UP_ABL      // timing ablations (results are WRONG): bit 0 no output stores, bit 1 no activation loads
 #define GTTS_UP_ABL 0
 #endif
 #ifndef GTTS_UP_NRP
@@ -307,7 +312,11 @@ __global__ __launch_bounds__(256 * NRP, 2) void conv_up4_f8_kernel(const ConvArg
         for (int it = 0; it < UP8_LITER; ++it)
 #pragma unroll
             for (int i = 0; i < 8; ++i)
+#if GTTS_UP_ABL & 2      // timing ablation: no activation loads
+                raw[it][i] = (float)(soff & 3);
+#else
                 raw[it][i] = it_off[it] >= 0 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, it_off[it], soff + i * HW * 4, 0)) : 0.f;
+#endif
     };
     auto stage_chunk = [&](int buf) {
         typedef __attribute__((ext_vector_type(2))) int i32x2;
@@ -455,7 +464,7 @@ __global__ __launch_bounds__(256 * NRP, 2) void conv_up4_f8_kernel(const ConvArg
                     u32x2 v;
                     v[0] = __builtin_bit_cast(unsigned, px ? oth : own);
                     v[1] = __builtin_bit_cast(unsigned, px ? own : oth);
-#if GTTS_UP_ABL == 1      // timing ablation: no output stores
+#if GTTS_UP_ABL & 1      // timing ablation: no output stores
                     if (own != 12345.678f) continue;
 #endif
                     __builtin_amdgcn_raw_buffer_store_b64(v, rso, voff, (cur.cot * 64 + ch) * HWo * 4, GTTS_OUT_NT);

@@ -35,7 +35,7 @@
 // Producer waves: [0] barrier wait, [1] staging (load wait + transform + LDS write), [2] re-request (+ tile setup), [3] finish_tile.
 // GTTS_WS_EXP (diagnostic builds only): timing ablations, results are WRONG.  1: the consumers never reload weights,
 // 2: the producers never re-request activations, 3: the producers skip transform + LDS write, 4: the consumers never re-read
-// B fragments, 5: no MFMAs (f16 + fp8 form: 1, 4, 5 in the consumer loop; 2, 3 are common)
+// B fragments, 5: no MFMAs, 6: no output stores (f16 + fp8 form: 1, 4, 5, 6 in the consumer loop / epilogue; 2, 3 are common)
 #ifndef GTTS_DIAG
 #undef GTTS_WS_TRACE
 #undef GTTS_WS_EXP
@@ -451,6 +451,7 @@ void conv3x3_ws_kernel(const ConvArgs a) {
                                 const int voff = (oy * a.Wout + oxx + 4 * kg_l * HW) * AB;
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) {
+                                    if (GTTS_WS_EXP == 6 && v[i] != 12345.678f) continue;      // (ablation: no output stores)
                                     if constexpr (AB == 4 && GTTS_WS_EPI_AUX != 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v[i]), rs_out, voff, soff + i * HW * AB, GTTS_WS_EPI_AUX);
                                     else st_act<AT>(v[i], rs_out, voff, soff + i * HW * AB);
                                 }
