@@ -5,11 +5,11 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["plan.hip", "conv_mfma.hip", "conv_ws.hip", "conv_up.hip", "attn.hip", "misc.hip", "pack.hip", "mas.hip", "vc.hip", "glue.hip", "voc.hip", "enc.hip", "train.hip", "train_norm.hip", "train_wgrad.hip", "train_attn.hip", "train_elem.hip", "train_inglu.hip", "postnet.hip", "ubench.hip"]
+SOURCES = ["plan.hip", "conv_mfma.hip", "conv_ws.hip", "conv_up.hip", "conv_up_ws.hip", "attn.hip", "misc.hip", "pack.hip", "mas.hip", "vc.hip", "glue.hip", "voc.hip", "enc.hip", "train.hip", "train_norm.hip", "train_wgrad.hip", "train_attn.hip", "train_elem.hip", "train_inglu.hip", "postnet.hip", "ubench.hip"]
 HEADERS = ["common.h", "kernels.h", "conv1d.h", os.path.join("..", "..", "include", "gradtts_abi.h")]
 # The SLP vectoriser packs the GroupNorm / Mish / split arithmetic of the conv prologue into v_pk_*_f32.  Beside MFMAs a
 # packed f32 op costs more issue time than the two scalar ops it replaces (MI355X guide; measured here: -1.6 % per U-Net call).
-PER_FILE_FLAGS = {"conv_mfma.hip": ["-fno-slp-vectorize"], "conv_ws.hip": ["-fno-slp-vectorize"], "conv_up.hip": ["-fno-slp-vectorize"]}      # (attn.hip: measured the other way, 185 vs 173 us -- it is VALU-bound and profits from the packing)
+PER_FILE_FLAGS = {"conv_mfma.hip": ["-fno-slp-vectorize"], "conv_ws.hip": ["-fno-slp-vectorize"], "conv_up.hip": ["-fno-slp-vectorize"], "conv_up_ws.hip": ["-fno-slp-vectorize"]}      # (attn.hip: measured the other way, 185 vs 173 us -- it is VALU-bound and profits from the packing)
 LIB = os.path.join(HERE, os.environ.get("GTTS_LIB_NAME", "libgradtts_gfx950.so"))
 
 

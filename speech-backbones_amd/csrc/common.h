@@ -337,6 +337,14 @@ bool conv_up4_eligible(const ConvArgs &a);
 #endif
 bool conv_up4_f16f8_ok(int cin, int cout);
 const char *conv_up4_f8_name();      // the instance launch_conv_up4 launches for such layers (per-op tables)
+// conv_up_ws.hip: the wave-specialised form of the same (producer waves load, stage and STORE).  Built, parity-green, measured on one box
+// against conv_up.hip's uniform-wave kernel: 114.5 / 132.3 us against 110 / 142.6 (128- / 64-channel layer) -- level; OFF (1: A/B builds)
+#ifndef GTTS_UP_WS
+#define GTTS_UP_WS 0
+#endif
+bool conv_up4_ws_ok(int cin, int cout);
+const char *conv_up4_ws_name();
+hipError_t launch_conv_up4_ws(const ConvArgs &a, hipStream_t st);
 hipError_t launch_conv_up4(const ConvArgs &a, hipStream_t st);
 // Block convolutions that take the f16 + fp8 split when the plan's precision is GTTS_PREC_F16F8 (conv_mfma.hip): 3x3, whole
 // 32-channel chunks (a concatenated input splitting on one), mask / GroupNorm prologue, statistics epilogue, and an LDS

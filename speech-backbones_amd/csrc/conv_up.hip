@@ -502,6 +502,7 @@ hipError_t launch_conv_up4(const ConvArgs &a_in, hipStream_t st) {
     a.tiles_y = (a.Hin + UP_TR - 1) / UP_TR;
     const long grid = (long)a.B * a.tiles_x * a.tiles_y * (a.cout / 64);
     if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
+    if (a.f16f8 && conv_up4_f16f8_ok(a.cin, a.cout) && conv_up4_ws_ok(a.cin, a.cout)) return launch_conv_up4_ws(a, st);
     if (a.f16f8 && conv_up4_f16f8_ok(a.cin, a.cout)) {
         // persistent: GTTS_UP_NRP = 2: one eight-wave workgroup per CU; 1: two four-wave workgroups per CU on 2-row tiles
         constexpr int NRP = GTTS_UP_NRP;

@@ -1468,7 +1468,7 @@ static std::string conv_kernel_name(int mode, int cin, int cout, int pro, int ep
         return wb;
     }
     if (mode == CONV_UP && nsplit == 2 && !abf && cin % 16 == 0 && pro == PRO_MASK && epi == EPI_PLAIN)      // conv_up.hip
-        return (up_f8 && conv_up4_f16f8_ok(cin, cout)) ? conv_up4_f8_name() : "gtts::conv_up4_kernel";
+        return (up_f8 && conv_up4_f16f8_ok(cin, cout)) ? (conv_up4_ws_ok(cin, cout) ? conv_up4_ws_name() : conv_up4_f8_name()) : "gtts::conv_up4_kernel";
     const int kch = conv_geom(mode, cin, cout, f8 ? 1 : 0).kch;
     if (f8) nsplit = 3;
     const bool fullc = cin % 16 == 0;

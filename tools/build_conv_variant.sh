@@ -8,7 +8,7 @@ while [ $# -gt 0 ]; do
   name=$1; flags=$2; shift 2
   (
   D=build/libgtts_$name; mkdir -p $D
-  for f in conv_ws conv_mfma conv_up; do
+  for f in conv_ws conv_mfma conv_up conv_up_ws; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-slp-vectorize $flags -c csrc/$f.hip -o $D/$f.o &
   done
   wait
