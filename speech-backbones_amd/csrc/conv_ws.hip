@@ -35,7 +35,7 @@
 // Producer waves: [0] barrier wait, [1] staging (load wait + transform + LDS write), [2] re-request (+ tile setup), [3] finish_tile.
 // GTTS_WS_EXP (diagnostic builds only): timing ablations, results are WRONG.  1: the consumers never reload weights,
 // 2: the producers never re-request activations, 3: the producers skip transform + LDS write, 4: the consumers never re-read
-// B fragments, 5: no MFMAs, 6: no output stores (f16 + fp8 form: 1, 4, 5, 6 in the consumer loop / epilogue; 2, 3 are common)
+// B fragments, 5: no MFMAs, 6: no output stores, 7: no weight loads in the first three taps of a tile (f16 + fp8 form: 1, 4, 5, 6 in the consumer loop / epilogue; 2, 3 are common)
 #ifndef GTTS_DIAG
 #undef GTTS_WS_TRACE
 #undef GTTS_WS_EXP
@@ -654,10 +654,15 @@ void conv3x3_ws_kernel(const ConvArgs a) {
                     if (u < 9) wload(w, cc, u / 3, u % 3, tl.cot);
                     else wload(w, ncn, (u - 9) / 3, (u - 9) % 3, tl.cot);
                 };
+                // (ablation 7: taps 0..2 of every tile but the first run on stale weight registers -- what a tile start that issues no
+                // vector load behind the previous tile's stores for three taps would gain)
+                const bool abl7 = GTTS_WS_EXP == 7 && i != 0 && cc == 0;
                 if (cc == 0) {
                     // a tile starts cold: its first weight sets are requested here (one exposed round trip per tile)
+                    if (!abl7) {
 #pragma unroll
                     for (int q = 0; q + 1 < NWS; ++q) wload_tap(wq[q], q);
+                    }
 #pragma unroll
                     for (int r = 0; r < FR; ++r)
 #pragma unroll
@@ -684,7 +689,7 @@ void conv3x3_ws_kernel(const ConvArgs a) {
                         const bool last_t = st == 2 && j == 2;
                         const int nst = j == 2 ? st + 1 : st, nj = j == 2 ? 0 : j + 1;      // next tap inside the chunk
                         // the set of tap + NWS - 1, NWS - 1 taps ahead
-                        if (GTTS_WS_EXP != 1) wload_tap(wq[NWS - 1], st * 3 + j + NWS - 1);
+                        if (GTTS_WS_EXP != 1 && !(abl7 && st == 0 && j < 2)) wload_tap(wq[NWS - 1], st * 3 + j + NWS - 1);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int s2 = 0; s2 < NS; ++s2) {
